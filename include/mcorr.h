@@ -1,0 +1,167 @@
+/* libmcorr -- MI355X (gfx950) motion-correction kernels, C ABI.
+ *
+ * Drop-in boundary for the estimate -> correct hot path of
+ * teamtomo/torch-motion-correction.  The reference has no FFI of its own (it is pure
+ * Python on torch ops), so these entry points are what a
+ * binding of that path needs: plain device pointers, sizes and a hipStream_t passed
+ * as void*.  No torch types appear here.  Every function is asynchronous on
+ * `stream`, allocates nothing, never synchronises, and returns 0 (MC_OK), a negative
+ * MC_ERR_* code, or a positive hipError_t from the launch.
+ *
+ * All pointers are DEVICE pointers unless marked (host).  Complex values are
+ * interleaved float pairs (re, im).  The Python host layer that mirrors the
+ * reference's function signatures on top of this ABI is
+ * torch_motion_correction_amd/ (ctypes); INTEGRATION.md shows the binding.
+ *
+ * Reference citations are relative to /root/reference/src/torch_motion_correction/.
+ */
+#ifndef MCORR_H
+#define MCORR_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCORR_ABI_VERSION 1
+int mc_abi_version(void);
+
+/* Geometry of one pruned 2-D real transform (host struct, passed by pointer).
+ * W,H: transform size (powers of two: 32<=W<=8192, 16<=H<=4096).
+ * nkx: kept rfft columns [0,nkx).  kyp,kyn: kept ky rows [0,kyp) U [H-kyn,H).
+ * [y0,y0+ny) x [x0,x1): window region that can be non-zero (support of the mask);
+ * ny and H must be multiples of RG (rows per workgroup, 1..16); x0,x1 even. */
+typedef struct mc_xc_geom {
+  int W, H, nkx, kyp, kyn, y0, ny, x0, x1, RG;
+} mc_xc_geom;
+
+/* ---- plan constants ------------------------------------------------------------ */
+
+/* Soft-edged disk mask (h*w floats): replaces torch_grid_utils.circle as called at
+ * estimate_motion_xc.py:69-74 and :262-264 -- 1 where |p-c| < radius (c = (h//2,w//2)),
+ * cos(pi/2 * d/smoothing_radius) of the exact Euclidean distance transform d to the
+ * disk for 0 < d <= smoothing_radius, else 0.  halfw: scratch of h ints. */
+int mc_circle_mask(float* mask, int* halfw, int h, int w, float radius, float smoothing_radius,
+                   void* stream);
+
+/* Combined band-pass * B-factor envelope on the pruned grid, filt[kx][kyi]
+ * (nkx * (kyp+kyn) floats): replaces b_envelope (estimate_motion_xc.py:81-88,:266-273)
+ * and prepare_bandpass_filter/bandpass_filter (utils.py:87-114) -- value
+ * exp(-B*(f/pixel_size)^2/4) where low < f <= high (cycles/px), else 0. */
+int mc_xc_filter(float* filt, const mc_xc_geom* geom, float low, float high, float b_factor,
+                 float pixel_size, void* stream);
+
+/* ---- a2: normalize_image statistics (utils.py:49-84) ---------------------------- */
+/* mean and unbiased std of stack[:, hl:hu, wl:wu] over all t frames jointly.
+ * acc: 2 doubles of scratch; out3 = {mean, 1/std, std} as floats. */
+int mc_central_box_stats(const float* stack, int t, int h, int w, int hl, int hu, int wl, int wu,
+                         double* acc, float* out3, void* stream);
+/* dst = (src - mean) * (1/std), n elements (normalize_image's elementwise pass). */
+int mc_normalize(const float* src, float* dst, int64_t n, const float* mean_rstd, void* stream);
+
+/* ---- a1/a6/a8: cross-correlation shift search ----------------------------------- */
+/* Dynamic LDS bytes K1/K4 need for this geometry (host helper). */
+int mc_xc_rows_lds_bytes(const mc_xc_geom* geom);
+
+/* K1.  For each job j: window origin src + job_off[j], rows row_stride floats apart;
+ * each sample becomes (x-mean)*rstd*mask^expo[j] (mask: H*W floats or NULL;
+ * mean_rstd NULL = no normalisation; job_expo NULL = exponent 1); real FFT along x;
+ * first nkx bins -> T1[j][kx][ny] (complex).  estimate_motion_xc.py:66,77-78 / :339-345. */
+int mc_xc_rows_forward(const float* src, const int64_t* job_off, int64_t row_stride,
+                       const int* job_expo, const float* mask, const float* mean_rstd, void* T1,
+                       const void* tw_row, int njobs, const mc_xc_geom* geom, void* stream);
+
+/* K2.  Column FFT of T1, kept ky rows, times filt (or NULL) -> S[j][kx][kyi].
+ * estimate_motion_xc.py:78,98 / :340-346. */
+int mc_xc_cols_forward(const void* T1, const float* filt, void* S, const void* tw_col, int njobs,
+                       const mc_xc_geom* geom, void* stream);
+
+/* K3.  pair p: conj(S_ref[ref_idx[p]]) * S_cur[cur_idx[p]] * scale, inverse column FFT
+ * -> T2[p][kx][H].  estimate_motion_xc.py:112-113 / :349-350. */
+int mc_xc_cols_inverse(const void* S_cur, const int* cur_idx, const void* S_ref,
+                       const int* ref_idx, void* T2, const void* tw_col, float scale, int npairs,
+                       const mc_xc_geom* geom, void* stream);
+
+/* K4+K5.  Inverse real row FFT of T2 fused with the arg-max (first maximum, as
+ * torch.argmax): peaks[p] = flat index y*W+x, shifts[p] = (sy,sx) after the
+ * wrap-around rule `p if p <= n//2 else p-n`.  part_val/part_idx: scratch of
+ * npairs*(H/RG) entries.  estimate_motion_xc.py:113-121 / :350-355,368-369. */
+int mc_xc_rows_inverse_argmax(const void* T2, float* part_val, int* part_idx, int* peaks,
+                              float* shifts, const void* tw_row, int npairs,
+                              const mc_xc_geom* geom, void* stream);
+
+/* K6.  nb[p][3][3]: correlation values at (py-1..py+1, px-1..px+1) around peaks[p]
+ * (NaN outside the map), same arithmetic as K4.  Feeds the parabola fit of
+ * _apply_sub_pixel_refinement, estimate_motion_xc.py:414-483. */
+int mc_xc_peak_neighbourhood(const void* T2, const int* peaks, float* nb, const void* tw_row,
+                             int npairs, const mc_xc_geom* geom, void* stream);
+
+/* Reference spectra for reference_strategy="mean_except_current"
+ * (estimate_motion_xc.py:310-328 + the in-place mask aliasing):
+ * REF[f][g] = inv_count * sum_{o != f} (table[f*t+o] ? V[o][g] : U[o][g]),
+ * spectra of `len` complex values, g in [0,npatch).  table: t*t bytes (device). */
+int mc_xc_ref_mean_except_current(const void* U, const void* V, const uint8_t* table, void* REF,
+                                  int t, int npatch, int64_t len, float inv_count, void* stream);
+
+/* ---- a11/a12/a13: per-frame shift post-processing ------------------------------- */
+/* Sub-pixel parabola (rules Q4/Q5), wrap-around, outlier rejection
+ * (estimate_motion_xc.py:538-627) and accumulation into field (2,t,gh,gw) [Angstrom]
+ * for `nf` frames: pair index p = fi*npatch + g maps to frame frames[fi].
+ * flags bit0 = sub_pixel_refinement, bit1 = outlier_rejection. */
+int mc_field_accumulate(const int* peaks, const float* nb, const int* frames, int nf, int npatch,
+                        int P, int t, float pixel_spacing, float outlier_threshold, int flags,
+                        float* field, void* stream);
+/* Savitzky-Golay (polyorder 1, mode "interp") along t for each (c,gy,gx), as
+ * scipy.signal.savgol_filter at estimate_motion_xc.py:528-529; then (optional)
+ * subtraction of the single global mean (xc.py:410).  field_out may alias field_in
+ * only if window < 3. */
+int mc_field_smooth_center(const float* field_in, float* field_out, int t, int npatch, int window,
+                           int subtract_mean, void* stream);
+
+/* ---- a14/a16: cubic spline grids ------------------------------------------------- */
+/* Evaluate a (c,nt,nh,nw) uniform cubic spline grid on the tensor-product lattice
+ * given by per-axis tap tables: for lattice coordinate i of an axis, 4 sample indices
+ * idx_*[4*i+k] and 4 weights w_*[4*i+k] (basis weights of the Catmull-Rom or B-spline
+ * matrix with the library's linear-extrapolation edge samples folded in by the host).
+ * out[c][NT][NY][NX].  Replaces CubicCatmullRomGrid3d / CubicBSplineGrid3d as used by
+ * deformation_field_utils.py:9-39,42-93,96-126. */
+int mc_spline_lattice(const float* data, int c, int nt, int nh, int nw, const int* idx_t,
+                      const float* w_t, int NT, const int* idx_y, const float* w_y, int NY,
+                      const int* idx_x, const float* w_x, int NX, float* out, void* stream);
+
+/* ---- a15/a17/a18: deformation-field warp ------------------------------------------ */
+/* lattice: (nframes, 2, GH, GW) Angstrom shifts on the 10x-oversampled lattice
+ * (evaluate_deformation_field_at_t, correct_motion.py:67-72).  For every frame:
+ * bicubic/reflection upsample to per-pixel shifts (get_pixel_shifts,
+ * correct_motion.py:132-185), then bicubic/border resample of the frame at
+ * pixel + shift/pixel_spacing with zero outside (_correct_frame + sample_image_2d,
+ * correct_motion.py:81-129).  scratch: mc_warp_scratch_bytes() bytes, 16-byte aligned.
+ * out_frames (nframes*h*w) and/or out_sum (h*w, accumulated with +=; caller zeroes)
+ * may be NULL (not both). */
+int mc_warp_scratch_bytes(int nframes, int h, int w, int GH, int GW, int64_t* bytes /*host*/);
+int mc_warp_frames(const float* frames, int nframes, int h, int w, const float* lattice, int GH,
+                   int GW, float pixel_spacing, float* scratch, float* out_frames, float* out_sum,
+                   void* stream);
+
+/* get_pixel_shifts (correct_motion.py:132-185) for one (2,GH,GW) lattice: out (h,w,2)
+ * shifts in px.  scratch: mc_warp_scratch_bytes(1,h,w,GH,GW). */
+int mc_pixel_shifts(const float* lattice, int GH, int GW, int h, int w, float pixel_spacing,
+                    float* scratch, float* out, void* stream);
+
+/* correct_motion_fast (correct_motion.py:430-498): K3 variant multiplying spectrum
+ * idx[p] by exp(-2*pi*i*(fy*sy+fx*sx)), shifts[p]=(sy,sx) px, then inverse columns. */
+int mc_fourier_shift_cols_inverse(const void* S, const int* idx, const float* shifts, void* T2,
+                                  const void* tw_col, float scale, int nframes,
+                                  const mc_xc_geom* geom, void* stream);
+/* K4 variant storing real rows: out + out_off[p] + y*out_stride. */
+int mc_xc_rows_inverse_store(const void* T2, float* out, const int64_t* out_off,
+                             int64_t out_stride, const void* tw_row, int nframes,
+                             const mc_xc_geom* geom, void* stream);
+
+/* caller-side frame sum (examples/ttMotion.py:398): sum[h*w] = sum_t frames[t]. */
+int mc_sum_frames(const float* frames, int nframes, int64_t hw, float* sum, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCORR_H */

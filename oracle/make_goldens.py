@@ -1,0 +1,170 @@
+"""Generate tests/golden/*.npz.  TEST INFRASTRUCTURE ONLY.
+
+Run in the build container (where /root/reference exists):
+
+    python -m oracle.make_goldens
+
+Two kinds of vectors are written:
+
+* ``patch_grid_reference.npz`` -- produced by the REFERENCE's own code: its
+  ``patch_grid`` sub-package is importable on its own (it only needs torch+einops;
+  the package ``__init__`` is bypassed because it eagerly imports the five absent
+  teamtomo dependencies).  Contents: 1-D patch centres for the BASELINE.json
+  shapes, a full lazy gather on a small stack, and the mask-exponent tables that
+  result from replaying the reference's per-frame loop (xc.py:297-346) on the
+  reference's LazyPatchGrid with a scalar "mask" of 2.0 (log2 of the value read =
+  number of times that memo entry had been multiplied in place).
+* ``oracle_*.npz`` -- outputs of the oracle itself (parity unpinned at the
+  third-party boundaries) on the reference's test fixtures and on the SURVEY
+  section 8d synthetic drift stack; used as regression pins and as the expected
+  values for the GPU parity tests.
+"""
+
+from __future__ import annotations
+
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+REF_SRC = "/root/reference/src/torch_motion_correction"
+
+
+def _reference_patch_grid():
+    pkg = types.ModuleType("torch_motion_correction")
+    pkg.__path__ = [REF_SRC]
+    sys.modules["torch_motion_correction"] = pkg
+    return importlib.import_module("torch_motion_correction.patch_grid")
+
+
+def reference_vectors():
+    pg = _reference_patch_grid()
+    centers_mod = importlib.import_module("torch_motion_correction.patch_grid._patch_grid_centers")
+    out = {}
+    # 1-D centres for every (dim_length, patch, step) the configs need
+    cases = [(64, 32), (512, 128), (256, 64), (4096, 1024), (4092, 1024), (5760, 1024),
+             (8184, 1024), (11520, 1024), (100, 32), (33, 32), (30, 32), (959, 256), (927, 256)]
+    for n, p in cases:
+        c = centers_mod._patch_centers_1d(dim_length=n, patch_length=p, patch_step=p // 2,
+                                          distribute_patches=True)
+        out[f"centers_{n}_{p}"] = c.numpy()
+    # full lazy gather on a small stack
+    g = torch.Generator().manual_seed(7)
+    img = torch.randn(3, 40, 52, generator=g)
+    lazy, centers = pg.patch_grid_lazy(images=img, patch_shape=(1, 16, 16), patch_step=(1, 8, 8),
+                                       distribute_patches=True)
+    out["gather_img"] = img.numpy()
+    out["gather_centers"] = centers.numpy()
+    out["gather_frame1"] = lazy[1].numpy()
+
+    # memo aliasing replay (Q2/Q3): exponent tables
+    def replay(t, strategy):
+        imgs = torch.ones(t, 8, 8)
+        lz, _ = pg.patch_grid_lazy(images=imgs, patch_shape=(1, 4, 4), patch_step=(1, 2, 2),
+                                   distribute_patches=True)
+        ref = t // 2
+        table = np.full((t, t), -1, dtype=np.int64)  # [frame, other] exponent when read
+        cur_exp = np.full((t,), -1, dtype=np.int64)
+        for f in range(t):
+            if strategy == "middle_frame":
+                if f == ref:
+                    continue
+                r = lz[ref]
+                table[f, ref] = int(torch.log2(r.flatten()[0]).item())
+                r = r.reshape(r.shape[1], r.shape[2], 4, 4)
+            else:
+                r = None
+                for o in range(t):
+                    if o == f:
+                        continue
+                    other = lz[o]
+                    table[f, o] = int(torch.log2(other.flatten()[0]).item())
+                    r = other.clone() if r is None else r + other
+            cur = lz[f]
+            cur_exp[f] = int(torch.log2(cur.flatten()[0]).item())
+            if strategy == "middle_frame":
+                r *= 2.0  # reshape of a contiguous tensor is a view, as einops.rearrange is
+            cur *= 2.0
+        return table, cur_exp
+
+    for t in (5, 8, 40, 51, 60):
+        for s in ("middle_frame", "mean_except_current"):
+            tab, cur = replay(t, s)
+            out[f"exp_{s}_{t}"] = tab
+            out[f"cur_{s}_{t}"] = cur
+    np.savez_compressed(os.path.join(GOLD, "patch_grid_reference.npz"), **out)
+    print("wrote patch_grid_reference.npz", len(out), "arrays")
+
+
+def blob_stack(moving: bool):
+    """tests/test_estimate_motion.py:13-33 and tests/test_correct_motion.py:15-32."""
+    t, h, w = 5, 64, 64
+    yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32),
+                            torch.arange(w, dtype=torch.float32), indexing="ij")
+    img = torch.zeros(t, h, w)
+    for f in range(t):
+        cy = (h // 2 + (2 * f if moving else 0)) % h
+        cx = (w // 2 + (f if moving else 0)) % w
+        img[f] = torch.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * 10**2))
+    return img
+
+
+def drift_stack(t, h, w, seed=1234, noise=1.0, pad=64):
+    """SURVEY.md section 8d synthetic recipe: white-noise texture, integer drift."""
+    g = torch.Generator().manual_seed(seed)
+    base = torch.randn(h + 2 * pad, w + 2 * pad, generator=g)
+    dy = torch.round(torch.linspace(-6, 8, t)).long()
+    dx = torch.round(torch.linspace(5, -4, t)).long()
+    frames = [
+        base[pad - dy[f] : pad - dy[f] + h, pad - dx[f] : pad - dx[f] + w]
+        + noise * torch.randn(h, w, generator=g)
+        for f in range(t)
+    ]
+    return torch.stack(frames), dy, dx
+
+
+def oracle_vectors():
+    import oracle
+
+    out = {}
+    mov, stat = blob_stack(True), blob_stack(False)
+    out["blob_global"] = oracle.estimate_global_motion(mov, 1.0).numpy()
+    for s in ("mean_except_current", "middle_frame"):
+        fld, pos = oracle.estimate_motion_cross_correlation_patches(
+            mov, 1.0, patch_sidelength=32, reference_strategy=s)
+        out[f"blob_patches_{s}"] = fld.numpy()
+    out["blob_patch_pos"] = pos.numpy()
+    f22 = torch.zeros(2, 5, 2, 2)
+    f11 = torch.zeros(2, 5, 1, 1)
+    for f in range(5):
+        f22[0, f], f22[1, f] = 0.1 * f, 0.05 * f
+        f11[0, f], f11[1, f] = 0.1 * f, 0.05 * f
+    out["blob_correct_cr"] = oracle.correct_motion(stat, f22, 1.0).numpy()
+    out["blob_correct_bs"] = oracle.correct_motion(stat, f22, 1.0, grid_type="bspline").numpy()
+    out["blob_fast"] = oracle.correct_motion_fast(stat, f11.clone()).numpy()
+    np.savez_compressed(os.path.join(GOLD, "oracle_blob.npz"), **out)
+
+    out = {}
+    st, dy, dx = drift_stack(8, 256, 256)
+    fld = oracle.estimate_global_motion(st, 1.0)
+    out["dy"], out["dx"] = dy.numpy(), dx.numpy()
+    out["global_field"] = fld.numpy()
+    out["corrected_sum"] = oracle.correct_motion(st, fld, 1.0).sum(0).numpy()
+    pf, pos = oracle.estimate_motion_cross_correlation_patches(st, 1.0, patch_sidelength=64)
+    out["patch_field"], out["patch_pos"] = pf.numpy(), pos.numpy()
+    out["patch_corrected_sum"] = oracle.correct_motion(st, pf, 1.0, grid_type="bspline").sum(0).numpy()
+    np.savez_compressed(os.path.join(GOLD, "oracle_drift_8x256.npz"), **out)
+    print("wrote oracle_*.npz")
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    if os.path.isdir(REF_SRC):
+        reference_vectors()
+    else:
+        print("reference not present: patch_grid_reference.npz not regenerated")
+    oracle_vectors()

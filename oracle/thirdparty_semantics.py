@@ -1,0 +1,245 @@
+"""Restated semantics of the reference's un-vendored third-party numerics.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  **Parity unpinned**: none of
+these packages is present in /root/reference, in the image, or pinned to a version
+by the reference (pyproject.toml:36-46 lists bare names); the reference's tests
+hold no numeric values for them.  Each function below restates the published
+behaviour of the call the reference makes and cites that call site.
+
+  torch_grid_utils        circle            estimate_motion_xc.py:69-74, :262-264
+                          coordinate_grid   correct_motion.py:106-109
+  torch_fourier_filter    b_envelope        estimate_motion_xc.py:81-88, :266-273
+                          bandpass_filter   utils.py:104-112
+  torch_fourier_shift     fourier_shift_dft_2d   correct_motion.py:488-494
+  torch_cubic_spline_grids  Cubic{BSpline,CatmullRom}Grid3d  deformation_field_utils.py:30-38
+  torch_image_interpolation sample_image_2d  correct_motion.py:123-127
+                            array_to_grid_sample correct_motion.py:170-172
+                            (an identical copy is utils.py:9-30)
+"""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from scipy import ndimage
+
+# --------------------------------------------------------------------------- grids
+
+
+def coordinate_grid(image_shape, center=None, norm=False, device=None):
+    """(h, w, 2) float32 grid of (y, x) array indices, optionally centred / normed."""
+    h, w = image_shape
+    yy, xx = torch.meshgrid(
+        torch.arange(h, dtype=torch.float32, device=device),
+        torch.arange(w, dtype=torch.float32, device=device),
+        indexing="ij",
+    )
+    grid = torch.stack([yy, xx], dim=-1)
+    if center is not None:
+        grid = grid - torch.as_tensor(center, dtype=torch.float32, device=device)
+    if norm:
+        grid = (grid**2).sum(dim=-1) ** 0.5
+    return grid
+
+
+def circle(radius, image_shape, center=None, smoothing_radius=0.0, device=None):
+    """Soft-edged disk: 1 where dist < radius, raised-cosine of the Euclidean
+    distance transform (scipy, float64 -> float32) over ``smoothing_radius`` px."""
+    h, w = image_shape
+    if center is None:
+        center = (h // 2, w // 2)
+    dist = coordinate_grid((h, w), center=center, norm=True)
+    inside = dist < radius
+    if smoothing_radius == 0:
+        return inside.float().to(device)
+    edt = ndimage.distance_transform_edt(torch.logical_not(inside).numpy())
+    edt = torch.as_tensor(edt).float()
+    soft = torch.logical_and(edt > 0, edt <= smoothing_radius)
+    out = inside.float()
+    out[soft] = torch.cos((torch.pi / 2) * (edt[soft] / smoothing_radius))
+    return out.to(device)
+
+
+def fftfreq_grid(image_shape, rfft, norm=False, device=None):
+    """(h, w', 2) grid of (fy, fx) in cycles/pixel, not fft-shifted."""
+    h, w = image_shape
+    fy = torch.fft.fftfreq(h, device=device)
+    fx = torch.fft.rfftfreq(w, device=device) if rfft else torch.fft.fftfreq(w, device=device)
+    gy, gx = torch.meshgrid(fy, fx, indexing="ij")
+    grid = torch.stack([gy, gx], dim=-1)
+    if norm:
+        grid = (grid**2).sum(dim=-1) ** 0.5
+    return grid
+
+
+# ------------------------------------------------------------------------- filters
+
+
+def b_envelope(B, image_shape, pixel_size, rfft=True, fftshift=False, device=None):
+    """exp(-B * (f / pixel_size)^2 / 4) on the (r)fft grid (amplitude divisor 4)."""
+    assert not fftshift
+    f = fftfreq_grid(image_shape, rfft=rfft, norm=True, device=device) / pixel_size
+    return torch.exp(-(B * f**2) / 4)
+
+
+def bandpass_filter(low, high, falloff, image_shape, rfft=True, fftshift=False, device=None):
+    """Float band ``low < f <= high`` (+ cosine falloff outside, width ``falloff``)."""
+    assert not fftshift
+    f = fftfreq_grid(image_shape, rfft=rfft, norm=True, device=device)
+    band = torch.logical_and(f > low, f <= high).float()
+    if falloff > 0:
+        lo = torch.logical_and(f > low - falloff, f <= low)
+        hi = torch.logical_and(f > high, f <= high + falloff)
+        band[lo] = torch.cos((torch.pi / 2) * ((f[lo] - low) / falloff))
+        band[hi] = torch.cos((torch.pi / 2) * ((f[hi] - high) / falloff))
+    return band
+
+
+def fourier_shift_dft_2d(dft, image_shape, shifts, rfft=True, fftshifted=False):
+    """Multiply a 2-D dft by exp(-2 pi i (fy*sy + fx*sx)); shifts (..., 2) in px."""
+    assert not fftshifted
+    grid = fftfreq_grid(image_shape, rfft=rfft, norm=False, device=dft.device)  # (h,w',2)
+    s = shifts[..., None, None, :]
+    ang = (-2 * torch.pi * grid * s).sum(dim=-1)
+    return dft * torch.complex(torch.cos(ang), torch.sin(ang))
+
+
+# ----------------------------------------------------------------- cubic spline grids
+
+_M_BSPLINE = (1.0 / 6.0) * torch.tensor(
+    [[1, 4, 1, 0], [-3, 0, 3, 0], [3, -6, 3, 0], [-1, 3, -3, 1]], dtype=torch.float32
+)
+_M_CATMULL_ROM = 0.5 * torch.tensor(
+    [[0, 2, 0, 0], [-1, 0, 1, 0], [2, -5, 4, -1], [-1, 3, -3, 1]], dtype=torch.float32
+)
+
+
+def spline_matrix(grid_type):
+    if grid_type == "catmull_rom":
+        return _M_CATMULL_ROM
+    if grid_type == "bspline":
+        return _M_BSPLINE
+    raise ValueError(f"unknown grid_type {grid_type}")
+
+
+def _axis_setup(n, u):
+    """Knots of a uniform axis with n samples on [0,1]; returns for each query the
+    lower-knot index il (into the *unpadded* axis, clipped to [0, n-2]) and the
+    fractional coordinate t in the interval [il, il+1]."""
+    pos = torch.linspace(0, 1, steps=n)
+    iu = torch.searchsorted(pos, u.contiguous(), side="right")
+    il = torch.clamp(iu - 1, 0, n - 2)
+    t = (u - pos[il]) * float(n - 1)
+    return il, t
+
+
+def _pad_axis(data, dim):
+    """Extend by one sample each side by linear extrapolation along ``dim``."""
+    n = data.shape[dim]
+    first = data.select(dim, 0)
+    second = data.select(dim, 1)
+    last = data.select(dim, n - 1)
+    penult = data.select(dim, n - 2)
+    start = first - (second - first)
+    end = last + (last - penult)
+    return torch.cat([start.unsqueeze(dim), data, end.unsqueeze(dim)], dim=dim)
+
+
+def _weights(t, M):
+    tv = torch.stack([torch.ones_like(t), t, t * t, t * t * t], dim=-1)  # (b,4)
+    return tv @ M  # (b,4)
+
+
+def cubic_spline_grid_3d(data, u, grid_type):
+    """Evaluate a (c, nt, nh, nw) uniform cubic spline grid at u (..., 3) in [0,1]^3.
+
+    Separable tricubic with the 4x4 basis matrix on [1,s,s^2,s^3]; the control
+    lattice is padded by one linearly extrapolated sample on each side; axes with a
+    single sample are treated as constant (duplicated to two samples).
+    Returns (..., c).
+    """
+    M = spline_matrix(grid_type)
+    data = data.detach().to(torch.float32).cpu()
+    lead = u.shape[:-1]
+    uu = u.detach().reshape(-1, 3).to(torch.float32).cpu()
+    for dim in (1, 2, 3):
+        if data.shape[dim] == 1:
+            data = torch.cat([data, data], dim=dim)
+    c = data.shape[0]
+    il_w = []
+    for a, dim in enumerate((1, 2, 3)):
+        il, t = _axis_setup(data.shape[dim], uu[:, a])
+        il_w.append((il, _weights(t, M)))
+    padded = data
+    for dim in (1, 2, 3):
+        padded = _pad_axis(padded, dim)
+    off = torch.arange(4)
+    it = (il_w[0][0][:, None] + off)[:, :, None, None]  # padded index = il-1+1+k
+    iy = (il_w[1][0][:, None] + off)[:, None, :, None]
+    ix = (il_w[2][0][:, None] + off)[:, None, None, :]
+    cp = padded[:, it, iy, ix]  # (c, b, 4, 4, 4)
+    wt, wy, wx = il_w[0][1], il_w[1][1], il_w[2][1]
+    v = (cp * wx[None, :, None, None, :]).sum(-1)  # along w
+    v = (v * wy[None, :, None, :]).sum(-1)  # along h
+    v = (v * wt[None, :, :]).sum(-1)  # along t  -> (c, b)
+    return v.transpose(0, 1).reshape(*lead, c)
+
+
+# ------------------------------------------------------------------ image sampling
+
+
+def array_to_grid_sample(array_coordinates, array_shape):
+    """Array coords (..., d) -> grid_sample coords (align_corners=True), flipped."""
+    shape = torch.as_tensor(
+        array_shape, dtype=array_coordinates.dtype, device=array_coordinates.device
+    )
+    g = (array_coordinates / (0.5 * shape - 0.5)) - 1
+    return torch.flip(g, dims=(-1,))
+
+
+def sample_image_2d(image, coordinates, interpolation="bicubic"):
+    """Sample (h, w) ``image`` at (..., 2) yx array coordinates: grid_sample with
+    border padding and align_corners=True, samples whose coordinate lies outside
+    [0, h-1] x [0, w-1] set to zero."""
+    h, w = image.shape[-2:]
+    lead = coordinates.shape[:-1]
+    coords = coordinates.reshape(1, -1, 1, 2)
+    out = F.grid_sample(
+        image.reshape(1, 1, h, w),
+        array_to_grid_sample(coords, (h, w)),
+        mode=interpolation,
+        padding_mode="border",
+        align_corners=True,
+    ).reshape(-1)
+    c = coords.reshape(-1, 2)
+    hi = torch.as_tensor([h - 1, w - 1], dtype=c.dtype, device=c.device)
+    inside = torch.logical_and(c >= 0, c <= hi).all(dim=-1)
+    out = torch.where(inside, out, torch.zeros_like(out))
+    return out.reshape(lead)
+
+
+# ----------------------------------------------------------------- dose weighting
+
+
+def dose_weight_movie(movie_dft, image_shape, pixel_size, pre_exposure, dose_per_frame,
+                      voltage=300.0):
+    """Grant & Grigorieff (2015) exposure filter as used by the reference's example
+    pipeline (examples/ttMotion.py:331-351, crit_exposure_bfactor=-1).  Untested in
+    the reference: parity unpinned.  movie_dft (t, h, w/2+1) -> same."""
+    t = movie_dft.shape[0]
+    f = fftfreq_grid(image_shape, rfft=True, norm=True, device=movie_dft.device) / pixel_size
+    a, b, c = 0.24499, -1.6649, 2.8141
+    scale = 1.0 if voltage >= 300 else (0.8 if voltage >= 200 else 0.75)
+    f = torch.clamp(f, min=1e-6)
+    ncrit = (a * f**b + c) * scale
+    dose = pre_exposure + dose_per_frame * torch.arange(1, t + 1, dtype=torch.float32)
+    wts = torch.exp(-0.5 * dose[:, None, None] / ncrit[None])
+    norm = torch.sqrt((wts**2).sum(dim=0, keepdim=True))
+    return movie_dft * (wts / norm)
+
+
+__all__ = [n for n in dir() if not n.startswith("_")]
+_ = (math, np)

@@ -1,0 +1,35 @@
+"""MI355X-native (gfx950) drop-in for the estimate -> correct hot path of
+teamtomo/torch-motion-correction: same public function names and signatures
+(reference: src/torch_motion_correction/__init__.py:12-44), hand-written HIP kernels
+behind a C ABI (include/mcorr.h, libmcorr.so).  There is no CPU fallback."""
+
+from .api import (  # noqa: F401
+    correct_motion,
+    correct_motion_fast,
+    estimate_global_motion,
+    estimate_motion,
+    estimate_motion_cross_correlation_patches,
+    evaluate_deformation_field,
+    evaluate_deformation_field_at_t,
+    get_pixel_shifts,
+    image_shifts_to_deformation_field,
+    motion_correct_sum,
+    resample_deformation_field,
+)
+from ._lib import McorrError  # noqa: F401
+
+__all__ = [
+    "correct_motion",
+    "correct_motion_fast",
+    "get_pixel_shifts",
+    "evaluate_deformation_field",
+    "estimate_global_motion",
+    "estimate_motion_cross_correlation_patches",
+    "estimate_motion",
+    "motion_correct_sum",
+    "evaluate_deformation_field_at_t",
+    "resample_deformation_field",
+    "image_shifts_to_deformation_field",
+    "McorrError",
+]
+__version__ = "0.1.0"

@@ -1,0 +1,58 @@
+"""Build libmcorr.so (hand-written HIP kernels + C ABI) for gfx950, in-tree.
+
+``python -m torch_motion_correction_amd._build`` or ``build_library()``.
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels with the
+source tree to the GPU box.
+"""
+
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
+LIB_PATH = os.path.join(PKG_DIR, "libmcorr.so")
+SOURCES = ["plan_stats.hip", "xc_fft.hip", "field_post.hip", "warp.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+
+
+def _stale(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    mt = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > mt for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(INCLUDE, "mcorr.h"))
+    objdir = os.path.join(PKG_DIR, "build")
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        srcp = os.path.join(CSRC, src)
+        if force or _stale(obj, [srcp] + headers):
+            cmd = [HIPCC, *FLAGS, f"-I{INCLUDE}", f"-I{CSRC}", "-c", srcp, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    if force or _stale(LIB_PATH, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

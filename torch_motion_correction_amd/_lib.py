@@ -1,0 +1,113 @@
+"""ctypes binding of libmcorr.so (the C ABI declared in include/mcorr.h).
+
+There is deliberately no fallback: if the library is missing or a call fails the
+caller gets an exception.  Nothing here touches the oracle.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libmcorr.so")
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class XcGeom(C.Structure):
+    """mirror of ``mc_xc_geom``"""
+
+    _fields_ = [(n, C.c_int) for n in ("W", "H", "nkx", "kyp", "kyn", "y0", "ny", "x0", "x1", "RG")]
+
+    @property
+    def nky(self) -> int:
+        return self.kyp + self.kyn
+
+
+GP = C.POINTER(XcGeom)
+
+# name -> argtypes; every function returns int
+SIGNATURES = {
+    "mc_abi_version": [],
+    "mc_circle_mask": [vp, vp, i32, i32, f32, f32, vp],
+    "mc_xc_filter": [vp, GP, f32, f32, f32, f32, vp],
+    "mc_central_box_stats": [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp],
+    "mc_normalize": [vp, vp, i64, vp, vp],
+    "mc_xc_rows_lds_bytes": [GP],
+    "mc_xc_rows_forward": [vp, vp, i64, vp, vp, vp, vp, vp, i32, GP, vp],
+    "mc_xc_cols_forward": [vp, vp, vp, vp, i32, GP, vp],
+    "mc_xc_cols_inverse": [vp, vp, vp, vp, vp, vp, f32, i32, GP, vp],
+    "mc_xc_rows_inverse_argmax": [vp, vp, vp, vp, vp, vp, i32, GP, vp],
+    "mc_xc_peak_neighbourhood": [vp, vp, vp, vp, i32, GP, vp],
+    "mc_xc_ref_mean_except_current": [vp, vp, vp, vp, i32, i32, i64, f32, vp],
+    "mc_field_accumulate": [vp, vp, vp, i32, i32, i32, i32, f32, f32, i32, vp, vp],
+    "mc_field_smooth_center": [vp, vp, i32, i32, i32, i32, vp],
+    "mc_spline_lattice": [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, i32, vp, vp],
+    "mc_warp_scratch_bytes": [i32, i32, i32, i32, i32, C.POINTER(C.c_int64)],
+    "mc_warp_frames": [vp, i32, i32, i32, vp, i32, i32, f32, vp, vp, vp, vp],
+    "mc_pixel_shifts": [vp, i32, i32, i32, i32, f32, vp, vp, vp],
+    "mc_fourier_shift_cols_inverse": [vp, vp, vp, vp, vp, f32, i32, GP, vp],
+    "mc_xc_rows_inverse_store": [vp, vp, vp, i64, vp, i32, GP, vp],
+    "mc_sum_frames": [vp, i32, i64, vp, vp],
+}
+
+_lib = None
+
+
+class McorrError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libmcorr.so; raises McorrError (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise McorrError(
+            f"{LIB_PATH} not found: build it with `python -m torch_motion_correction_amd._build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    if lib.mc_abi_version() != 1:
+        raise McorrError("libmcorr ABI version mismatch; rebuild the library")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        kind = {-1: "bad argument", -2: "unsupported size/mode"}.get(rc, f"hipError {rc}")
+        raise McorrError(f"{what} failed: {kind}")
+
+
+def ptr(t):
+    """device pointer of a tensor (or None)"""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "libmcorr needs contiguous buffers"
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_gpu(device=None) -> torch.device:
+    """The product path runs on the MI355X only."""
+    if not torch.cuda.is_available():
+        raise McorrError(
+            "torch_motion_correction_amd needs a ROCm GPU (gfx950); no GPU is visible and there "
+            "is no CPU fallback"
+        )
+    if device is None or torch.device(device).type != "cuda":
+        return torch.device("cuda", torch.cuda.current_device())
+    d = torch.device(device)
+    return d if d.index is not None else torch.device("cuda", torch.cuda.current_device())

@@ -1,0 +1,234 @@
+"""Reference-compatible Python entry points (same names, argument order, defaults,
+shapes, units and error behaviour as torch_motion_correction's public API,
+src/torch_motion_correction/__init__.py:12-44), executing on the MI355X through
+libmcorr.  No CPU fallback exists: without a ROCm device these raise McorrError.
+
+Device rule (reference: ``device=None`` -> ``image.device``): results are returned on
+the device the reference would have returned them on; when that device is the CPU,
+inputs are staged to the current GPU, computed there and copied back.
+
+``BUG_COMPATIBLE`` (default True) keeps the reference's behavioural accidents that
+change numbers or mutate arguments: the in-place negation of
+the caller's field in ``correct_motion_fast`` (Q1) and the mask-exponent schedule
+caused by the lazy-patch memo aliasing (Q2/Q3).  Q4-Q9 are plain semantics and are
+always reproduced.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from . import engine
+from ._lib import require_gpu
+
+BUG_COMPATIBLE = True
+VERBOSE = False  # the reference prints progress lines; opt in with VERBOSE = True
+
+
+def _say(msg: str):
+    if VERBOSE:
+        print(msg)
+
+
+def _out_device(image: torch.Tensor, device):
+    return image.device if device is None else torch.device(device)
+
+
+def _stage(x: torch.Tensor, dev) -> torch.Tensor:
+    return x.detach().to(device=dev, dtype=torch.float32).contiguous()
+
+
+# ------------------------------------------------------------------ field utilities
+
+
+def image_shifts_to_deformation_field(shifts, pixel_spacing, device=None):
+    """(t,2) px shifts -> (2,t,1,1) Angstrom field, no sign flip
+    (deformation_field_utils.py:129-162)."""
+    if device is not None:
+        shifts = shifts.to(device)
+    return (shifts * pixel_spacing).transpose(0, 1)[:, :, None, None]
+
+
+def evaluate_deformation_field(deformation_field, tyx, grid_type="catmull_rom"):
+    """(c,nt,nh,nw) spline grid evaluated at (...,3) tyx points in [0,1] -> (...,c)
+    (deformation_field_utils.py:9-39).  Points are evaluated one tensor-product row at
+    a time through the lattice kernel (a 1x1x1 lattice per point)."""
+    out_dev = deformation_field.device
+    dev = require_gpu(out_dev)
+    field = _stage(deformation_field, dev)
+    pts = tyx.detach().to(torch.float32).cpu().reshape(-1, 3)
+    lead = tyx.shape[:-1]
+    c = field.shape[0]
+    # group points that share (t, y): evaluate all their x at once
+    vals = torch.empty((pts.shape[0], c), dtype=torch.float32, device=dev)
+    keys = pts[:, :2].contiguous()
+    uniq, inverse = torch.unique(keys, dim=0, return_inverse=True)
+    for k in range(uniq.shape[0]):
+        sel = torch.nonzero(inverse == k).flatten()
+        lat = engine.spline_lattice(field, uniq[k, 0:1], uniq[k, 1:2], pts[sel, 2].contiguous(),
+                                    grid_type)  # (c,1,1,n)
+        vals[sel.to(dev)] = lat[:, 0, 0, :].transpose(0, 1)
+    return vals.reshape(*lead, c).to(out_dev)
+
+
+def evaluate_deformation_field_at_t(deformation_field, t, grid_shape, grid_type="catmull_rom"):
+    """(c, H, W) shifts on the linspace(0,1) lattice at time t
+    (deformation_field_utils.py:42-93)."""
+    out_dev = deformation_field.device
+    dev = require_gpu(out_dev)
+    H, W = grid_shape
+    lat = engine.spline_lattice(_stage(deformation_field, dev),
+                                torch.as_tensor([float(t)], dtype=torch.float32),
+                                torch.linspace(0, 1, steps=H), torch.linspace(0, 1, steps=W), grid_type)
+    return lat[:, 0].to(out_dev)
+
+
+def resample_deformation_field(deformation_field, target_resolution):
+    """Catmull-Rom resample to (nt,nh,nw) (deformation_field_utils.py:96-126)."""
+    out_dev = deformation_field.device
+    dev = require_gpu(out_dev)
+    nt, nh, nw = target_resolution
+    lat = engine.spline_lattice(_stage(deformation_field, dev), torch.linspace(0, 1, steps=nt),
+                                torch.linspace(0, 1, steps=nh), torch.linspace(0, 1, steps=nw),
+                                "catmull_rom")
+    return lat.to(out_dev)
+
+
+# ------------------------------------------------------------------ estimators
+
+
+def estimate_global_motion(image, pixel_spacing, reference_frame=None, b_factor=500,
+                           frequency_range=(300, 10), device=None):
+    """Whole-frame cross-correlation shift estimate (estimate_motion_xc.py:21-135).
+    Returns the (2,t,1,1) float32 deformation field in Angstrom (integer px shifts x
+    pixel_spacing; the reference frame's entry is exactly 0)."""
+    out_dev = _out_device(image, device)
+    dev = require_gpu(out_dev)
+    img = _stage(image, dev)
+    t = img.shape[0]
+    ref = t // 2 if reference_frame is None else reference_frame
+    _say(f"Cross-correlation whole image: using frame {ref} as reference")
+    shifts = engine.global_shifts(img, ref, float(pixel_spacing), float(b_factor), frequency_range)
+    if VERBOSE:
+        _say(f"Estimated shifts range: y=[{shifts[:, 0].min():.1f}, {shifts[:, 0].max():.1f}], "
+             f"x=[{shifts[:, 1].min():.1f}, {shifts[:, 1].max():.1f}]")
+    return image_shifts_to_deformation_field(shifts, pixel_spacing).to(out_dev)
+
+
+def estimate_motion_cross_correlation_patches(
+    image, pixel_spacing, reference_frame=None, reference_strategy="mean_except_current",
+    b_factor=500, frequency_range=(300, 10), patch_sidelength=1024, sub_pixel_refinement=True,
+    temporal_smoothing=True, smoothing_window_size=5, deformation_field=None,
+    outlier_rejection=True, outlier_threshold=3.0, device=None,
+):
+    """Per-patch cross-correlation shift estimate (estimate_motion_xc.py:138-411).
+    Returns ((2,t,gh,gw) Angstrom field with its global mean subtracted,
+    (t,gh,gw,3) int64 patch centres)."""
+    out_dev = _out_device(image, device)
+    dev = require_gpu(out_dev)
+    img = _stage(image, dev)
+    t, h, w = img.shape
+    ref = t // 2 if reference_frame is None else reference_frame
+    if reference_strategy not in ("middle_frame", "mean_except_current"):
+        raise ValueError(f"Unknown reference_strategy: {reference_strategy}")
+    stats = engine.central_box_stats(img)  # statistics of the *uncorrected* stack (Q9)
+    field0 = None
+    if deformation_field is not None:
+        if deformation_field.device != out_dev:
+            deformation_field = deformation_field.clone()  # the reference's .to(device) copy
+        norm = engine.normalize(img, stats)
+        stats = None
+        if tuple(deformation_field.shape[-2:]) == (1, 1):
+            _say("Applying single patch deformation field using correct_motion_fast")
+            img = _correct_motion_fast_impl(norm, deformation_field, dev, mutate=BUG_COMPATIBLE)
+        else:
+            _say("Applying full deformation field using correct_motion")
+            lat = engine.frame_lattices(_stage(deformation_field, dev), t, "bspline")
+            img, _ = engine.warp(norm, lat, float(pixel_spacing))
+        # the prior field (after Q1's in-place negation, if any) is the accumulator base
+        from .lattice import patch_grid_centers
+
+        cy, cx = patch_grid_centers(t, h, w, int(patch_sidelength))
+        field0 = resample_deformation_field(_stage(deformation_field, dev), (t, len(cy), len(cx)))
+    field, centers = engine.patch_field(
+        img, stats, float(pixel_spacing), ref, reference_strategy, float(b_factor), frequency_range,
+        patch_sidelength, bool(sub_pixel_refinement), bool(temporal_smoothing),
+        int(smoothing_window_size), field0, bool(outlier_rejection), float(outlier_threshold))
+    return field.to(out_dev), centers.to(out_dev)
+
+
+def estimate_motion(image, pixel_spacing, patch_sidelength=None, **kwargs):
+    """Convenience alias (ours, not the reference's): global estimate when
+    ``patch_sidelength`` is None, else the patch estimate (field only)."""
+    if patch_sidelength is None:
+        return estimate_global_motion(image, pixel_spacing, **kwargs)
+    return estimate_motion_cross_correlation_patches(
+        image, pixel_spacing, patch_sidelength=patch_sidelength, **kwargs)[0]
+
+
+# ------------------------------------------------------------------ correctors
+
+
+def correct_motion(image, deformation_grid, pixel_spacing, grad=False, grid_type="catmull_rom",
+                   device=None):
+    """Apply a (2,nt,gh,gw) Angstrom deformation field (correct_motion.py:18-78).
+    Returns the (t,h,w) corrected frames, detached.  ``grad=True`` (autograd through
+    the resampling) is not available on the HIP path."""
+    if grad:
+        raise NotImplementedError("grad=True is not supported by the HIP path (forward only)")
+    out_dev = _out_device(image, device)
+    dev = require_gpu(out_dev)
+    img = _stage(image, dev)
+    lat = engine.frame_lattices(_stage(deformation_grid, dev), img.shape[0], grid_type)
+    frames, _ = engine.warp(img, lat, float(pixel_spacing), want_frames=True, want_sum=False)
+    return frames.to(out_dev)
+
+
+def motion_correct_sum(image, deformation_grid, pixel_spacing, grid_type="catmull_rom", device=None,
+                       return_frames=False):
+    """Fused correct_motion + the caller-side ``torch.sum(movie, dim=0)`` of the
+    reference's pipeline (examples/ttMotion.py:398): returns the (h,w) aligned sum
+    (and the frames when asked) without a second pass over the stack."""
+    out_dev = _out_device(image, device)
+    dev = require_gpu(out_dev)
+    img = _stage(image, dev)
+    lat = engine.frame_lattices(_stage(deformation_grid, dev), img.shape[0], grid_type)
+    frames, total = engine.warp(img, lat, float(pixel_spacing), want_frames=return_frames, want_sum=True)
+    return (total.to(out_dev), frames.to(out_dev)) if return_frames else total.to(out_dev)
+
+
+def _correct_motion_fast_impl(img_dev, deformation_grid, dev, mutate):
+    if tuple(deformation_grid.shape[-2:]) != (1, 1):
+        raise ValueError(
+            f"Expected single patch deformation field with shape (2, t, 1, 1), "
+            f"but got shape {deformation_grid.shape}. "
+            f"Final two dimensions must be (1, 1) for single patch correction."
+        )
+    shifts = -deformation_grid.detach()[:, :, 0, 0].transpose(0, 1).to(torch.float32)
+    if mutate:
+        deformation_grid.mul_(-1)  # Q1: correct_motion.py:473-474 negates the caller's tensor
+    return engine.fourier_shift(img_dev, shifts.to(dev))
+
+
+def correct_motion_fast(image, deformation_grid, device=None):
+    """Rigid correction by a Fourier phase ramp (correct_motion.py:430-498); field
+    values are used as pixels.  With BUG_COMPATIBLE the caller's `deformation_grid` is
+    negated in place exactly when the reference would do so (grid already on the
+    target device)."""
+    out_dev = _out_device(image, device)
+    dev = require_gpu(out_dev)
+    mutate = BUG_COMPATIBLE and (device is None or deformation_grid.device == torch.device(device))
+    out = _correct_motion_fast_impl(_stage(image, dev), deformation_grid, dev, mutate)
+    return out.to(out_dev)
+
+
+def get_pixel_shifts(frame, pixel_spacing, frame_deformation_grid, pixel_grid=None):
+    """(h,w,2) per-pixel shifts in px from a (2,G_h,G_w) Angstrom lattice
+    (correct_motion.py:132-185).  `pixel_grid` is accepted for signature parity; the
+    reference always passes the identity grid coordinate_grid((h,w)), which is what
+    the kernel evaluates."""
+    out_dev = frame.device
+    dev = require_gpu(out_dev)
+    h, w = frame.shape[-2:]
+    out = engine.pixel_shifts(_stage(frame_deformation_grid, dev), h, w, float(pixel_spacing))
+    return out.to(out_dev)

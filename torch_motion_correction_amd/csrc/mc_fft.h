@@ -1,0 +1,153 @@
+// Workgroup-cooperative power-of-two complex FFT for gfx950.
+//
+// One 256-thread workgroup (4 wave64) transforms one length-N line that lives in an
+// LDS buffer of interleaved complex values.  The algorithm is Stockham autosort
+// (natural order in, natural order out) with radix-8 passes and one trailing
+// radix-4/2 pass; each pass keeps its butterflies in registers between the
+// "read everything" and "write everything" halves so a single LDS line suffices.
+// The first pass pulls its inputs through a caller-supplied functor (fused
+// prologue: global load, normalise, mask, conj-multiply ...) and the last pass
+// pushes its outputs through a caller-supplied functor (fused epilogue: filter,
+// store, arg-max ...), so neither end of a transform needs an extra LDS round trip.
+//
+// LDS layout: cfloat line[lds_len(N)], element i at lpad(i) = i + (i >> 4)
+// (one pad element per 16: the strided writes of a radix-8 pass then fall on
+// distinct banks for ds_write_b64's 16-lane groups).
+#pragma once
+#include "mc_common.h"
+
+__device__ __forceinline__ int lpad(int i) { return i + (i >> 4); }
+__host__ __device__ constexpr int lds_len(int n) { return n + (n >> 4) + 1; }
+
+#define MC_SQRT1_2 0.70710678118654752440f
+
+template <int DIR>
+__device__ __forceinline__ void bfly2(cfloat* a) {
+  cfloat t = a[0];
+  a[0] = cadd(t, a[1]);
+  a[1] = csub(t, a[1]);
+}
+
+template <int DIR>
+__device__ __forceinline__ void bfly4(cfloat& a0, cfloat& a1, cfloat& a2, cfloat& a3) {
+  cfloat t0 = cadd(a0, a2), t1 = csub(a0, a2);
+  cfloat t2 = cadd(a1, a3), t3 = cmul_i<DIR>(csub(a1, a3));
+  a0 = cadd(t0, t2);
+  a1 = cadd(t1, t3);
+  a2 = csub(t0, t2);
+  a3 = csub(t1, t3);
+}
+
+template <int DIR>
+__device__ __forceinline__ void bfly8(cfloat* a) {
+  bfly4<DIR>(a[0], a[2], a[4], a[6]);  // E[k] in a0,a2,a4,a6
+  bfly4<DIR>(a[1], a[3], a[5], a[7]);  // O[k] in a1,a3,a5,a7
+  const float c = MC_SQRT1_2;
+  cfloat o1, o2, o3;
+  if (DIR < 0) {
+    o1 = cmake(c * (a[3].x + a[3].y), c * (a[3].y - a[3].x));
+    o3 = cmake(c * (a[7].y - a[7].x), -c * (a[7].x + a[7].y));
+  } else {
+    o1 = cmake(c * (a[3].x - a[3].y), c * (a[3].x + a[3].y));
+    o3 = cmake(-c * (a[7].x + a[7].y), c * (a[7].x - a[7].y));
+  }
+  o2 = cmul_i<DIR>(a[5]);
+  cfloat e0 = a[0], e1 = a[2], e2 = a[4], e3 = a[6], o0 = a[1];
+  a[0] = cadd(e0, o0);
+  a[4] = csub(e0, o0);
+  a[1] = cadd(e1, o1);
+  a[5] = csub(e1, o1);
+  a[2] = cadd(e2, o2);
+  a[6] = csub(e2, o2);
+  a[3] = cadd(e3, o3);
+  a[7] = csub(e3, o3);
+}
+
+template <int R, int DIR>
+__device__ __forceinline__ void bfly(cfloat* a) {
+  if constexpr (R == 8) bfly8<DIR>(a);
+  else if constexpr (R == 4) bfly4<DIR>(a[0], a[1], a[2], a[3]);
+  else bfly2<DIR>(a);
+}
+
+// One Stockham pass of radix R at sub-transform length NS (product of earlier
+// radices).  tw = table of exp(-2*pi*i*k/L), L = N * tw_stride.
+template <int N, int R, int NS, int DIR, bool SYNC_MID, bool SYNC_END, typename Load, typename Store>
+__device__ __forceinline__ void fft_pass(int tid, const cfloat* __restrict__ tw, int tw_stride,
+                                         Load load, Store store) {
+  constexpr int NB = N / R;
+  constexpr int IT = (NB + MC_WG - 1) / MC_WG;
+  cfloat v[IT][R];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int j = tid + it * MC_WG;
+    if (NB >= MC_WG || j < NB) {
+#pragma unroll
+      for (int m = 0; m < R; ++m) v[it][m] = load(j + m * NB);
+      if constexpr (NS > 1) {
+        const int k = j & (NS - 1);
+        cfloat w1 = tw[k * (N / (NS * R)) * tw_stride];
+        if (DIR > 0) w1.y = -w1.y;
+        v[it][1] = cmul(v[it][1], w1);
+        if constexpr (R >= 4) {
+          cfloat w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+          v[it][2] = cmul(v[it][2], w2);
+          v[it][3] = cmul(v[it][3], w3);
+          if constexpr (R == 8) {
+            cfloat w4 = cmul(w2, w2), w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3);
+            v[it][4] = cmul(v[it][4], w4);
+            v[it][5] = cmul(v[it][5], w5);
+            v[it][6] = cmul(v[it][6], w6);
+            v[it][7] = cmul(v[it][7], w7);
+          }
+        }
+      }
+      bfly<R, DIR>(v[it]);
+    }
+  }
+  if (SYNC_MID) __syncthreads();
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int j = tid + it * MC_WG;
+    if (NB >= MC_WG || j < NB) {
+      const int k = j & (NS - 1);
+      const int base = (j - k) * R + k;
+#pragma unroll
+      for (int m = 0; m < R; ++m) store(base + m * NS, v[it][m]);
+    }
+  }
+  if (SYNC_END) __syncthreads();
+}
+
+template <int N, int NS, int DIR, bool FIRST, typename Load, typename Store>
+__device__ __forceinline__ void fft_rec(cfloat* line, int tid, const cfloat* __restrict__ tw,
+                                        int tw_stride, Load load, Store store) {
+  constexpr int REM = N / NS;
+  constexpr int R = REM >= 8 ? 8 : REM;
+  constexpr bool LAST = (NS * R == N);
+  auto lds_load = [line](int i) { return line[lpad(i)]; };
+  auto lds_store = [line](int i, cfloat v) { line[lpad(i)] = v; };
+  if constexpr (FIRST && LAST) {
+    fft_pass<N, R, NS, DIR, false, false>(tid, tw, tw_stride, load, store);
+  } else if constexpr (FIRST) {
+    fft_pass<N, R, NS, DIR, false, true>(tid, tw, tw_stride, load, lds_store);
+    fft_rec<N, NS * R, DIR, false>(line, tid, tw, tw_stride, load, store);
+  } else if constexpr (LAST) {
+    fft_pass<N, R, NS, DIR, true, false>(tid, tw, tw_stride, lds_load, store);
+  } else {
+    fft_pass<N, R, NS, DIR, true, true>(tid, tw, tw_stride, lds_load, lds_store);
+    fft_rec<N, NS * R, DIR, false>(line, tid, tw, tw_stride, load, store);
+  }
+}
+
+// Length-N transform by the whole workgroup.  Preconditions: every thread of the
+// 256-thread workgroup calls it; nobody still reads `line` from an earlier use
+// (caller barriers).  DIR=-1 forward (exp(-i..)), DIR=+1 inverse, unscaled.
+// `load(i)` supplies input element i (each i exactly once, by some thread);
+// `store(i, v)` receives output element i.  If `store` writes `line` itself the
+// caller must barrier before reading it.
+template <int N, int DIR, typename Load, typename Store>
+__device__ __forceinline__ void wg_fft(cfloat* line, int tid, const cfloat* __restrict__ tw,
+                                       int tw_stride, Load load, Store store) {
+  fft_rec<N, 1, DIR, true>(line, tid, tw, tw_stride, load, store);
+}

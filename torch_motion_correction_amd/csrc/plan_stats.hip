@@ -1,0 +1,245 @@
+// Plan constants (mask, filter) and normalisation statistics.
+// All arithmetic that decides *which* pixels/bins are inside follows the fp32 op
+// order of the torch expressions the reference evaluates, without FMA contraction.
+#pragma clang fp contract(off)
+#include "mc_common.h"
+#include "mcorr.h"
+
+// ------------------------------------------------------------------ circle mask
+// torch_grid_utils.circle (xc.py:69-74): inside <=> sqrt(dy^2+dx^2) < radius in fp32.
+__device__ __forceinline__ bool disk_inside(int dy, int dx, float radius) {
+  const float fy = (float)dy, fx = (float)dx;
+  return sqrtf(fy * fy + fx * fx) < radius;
+}
+
+// halfw[y] = largest a >= 0 with (y, cx +- a) inside, or -1 when the row is empty.
+__global__ void mask_halfwidth(int* __restrict__ halfw, int h, int w, float radius) {
+  const int y = blockIdx.x * blockDim.x + threadIdx.x;
+  if (y >= h) return;
+  const int cy = h / 2;
+  int a = -1;
+  for (int dx = 0; dx <= w; ++dx) {
+    if (disk_inside(y - cy, dx, radius)) a = dx;
+    else break;
+  }
+  halfw[y] = a;
+}
+
+__global__ void mask_fill(float* __restrict__ mask, const int* __restrict__ halfw, int h, int w,
+                          float radius, float smoothing) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= w) return;
+  const int cy = h / 2, cx = w / 2;
+  const int dy = y - cy, dx = x - cx;
+  float out = 0.f;
+  if (disk_inside(dy, dx, radius)) {
+    out = 1.f;
+  } else if (smoothing > 0.f) {
+    const double D = sqrt((double)dy * dy + (double)dx * dx);
+    const double excess = D - (double)radius;
+    if (excess <= (double)smoothing + 2.0) {
+      // exact EDT to the digital disk: the nearest disk pixel is within excess+2 rows
+      const int reach = (int)excess + 3;
+      int lo = y - reach, hi = y + reach;
+      if (lo < 0) lo = 0;
+      if (hi > h - 1) hi = h - 1;
+      long long best = -1;
+      const int adx = dx < 0 ? -dx : dx;
+      for (int yy = lo; yy <= hi; ++yy) {
+        const int a = halfw[yy];
+        if (a < 0) continue;
+        // columns of the row that are inside and inside the image
+        int gap;
+        if (dx >= 0) {
+          int right = cx + a;
+          if (right > w - 1) right = w - 1;
+          gap = x - right;
+        } else {
+          int left = cx - a;
+          if (left < 0) left = 0;
+          gap = left - x;
+        }
+        (void)adx;
+        if (gap < 0) gap = 0;
+        const long long ddy = (long long)(y - yy);
+        const long long d2 = ddy * ddy + (long long)gap * gap;
+        if (best < 0 || d2 < best) best = d2;
+      }
+      if (best > 0) {
+        const float d = (float)sqrt((double)best);
+        if (d <= smoothing) {
+          const float halfpi = 1.5707963267948966f;
+          out = cosf(halfpi * (d / smoothing));
+        }
+      }
+    }
+  }
+  mask[(int64_t)y * w + x] = out;
+}
+
+// ------------------------------------------------------------------ xc filter
+// torch.fft.fftfreq / rfftfreq: k * (1/n); norm = sqrt(fy^2 + fx^2) in fp32.
+__global__ void xc_filter_fill(float* __restrict__ filt, int W, int H, int nkx, int kyp, int kyn,
+                               float low, float high, float B, float pixel_size) {
+  const int nky = kyp + kyn;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nkx * nky) return;
+  const int kx = i / nky, kyi = i - kx * nky;
+  const int ky = kyi < kyp ? kyi : kyi - kyp + (H - kyn);
+  const int kk = (ky < (H + 1) / 2) ? ky : ky - H;
+  const float fy = (float)kk * (float)(1.0 / (double)H);
+  const float fx = (float)kx * (float)(1.0 / (double)W);
+  const float f = sqrtf(fy * fy + fx * fx);
+  float v = 0.f;
+  if (f > low && f <= high) {
+    const float fp = f / pixel_size;
+    v = expf(-(B * (fp * fp)) / 4.f);
+  }
+  filt[i] = v;
+}
+
+// ------------------------------------------------------------------ statistics
+__global__ __launch_bounds__(256) void box_stats_partial(const float* __restrict__ stack, int h,
+                                                         int w, int hl, int hu, int wl, int wu,
+                                                         double* __restrict__ acc) {
+  // grid: (row chunks, t); each block reduces rows [r0, r1) of one frame's box
+  const int f = blockIdx.y;
+  const int rows_per = (hu - hl + gridDim.x - 1) / gridDim.x;
+  const int r0 = hl + blockIdx.x * rows_per;
+  int r1 = r0 + rows_per;
+  if (r1 > hu) r1 = hu;
+  const float* frame = stack + (int64_t)f * h * w;
+  double s = 0.0, q = 0.0;
+  for (int y = r0; y < r1; ++y) {
+    const float* row = frame + (int64_t)y * w;
+    float ps = 0.f, pq = 0.f;
+    int n = 0;
+    for (int x = wl + threadIdx.x; x < wu; x += 256) {
+      const float v = row[x];
+      ps += v;
+      pq += v * v;
+      if (++n == 16) {  // flush the fp32 partials regularly
+        s += ps; q += pq; ps = 0.f; pq = 0.f; n = 0;
+      }
+    }
+    s += ps;
+    q += pq;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_down(s, off);
+    q += __shfl_down(q, off);
+  }
+  __shared__ double ss[4], sq[4];
+  if ((threadIdx.x & 63) == 0) {
+    ss[threadIdx.x >> 6] = s;
+    sq[threadIdx.x >> 6] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s = ss[0] + ss[1] + ss[2] + ss[3];
+    q = sq[0] + sq[1] + sq[2] + sq[3];
+    atomicAdd(&acc[0], s);
+    atomicAdd(&acc[1], q);
+  }
+}
+
+__global__ void box_stats_final(const double* __restrict__ acc, double count,
+                                float* __restrict__ out3) {
+  const double mean = acc[0] / count;
+  double var = (acc[1] - acc[0] * acc[0] / count) / (count - 1.0);
+  if (var < 0) var = 0;
+  const float stdf = (float)sqrt(var);
+  out3[0] = (float)mean;
+  out3[1] = 1.0f / stdf;
+  out3[2] = stdf;
+}
+
+__global__ void normalize_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n,
+                                 const float* __restrict__ mean_rstd) {
+  const float mean = mean_rstd[0], stdv = mean_rstd[2];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    dst[i] = (src[i] - mean) / stdv;
+}
+
+__global__ void sum_frames_kernel(const float* __restrict__ frames, int nframes, int64_t hw,
+                                  float* __restrict__ sum) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < hw; i += stride) {
+    if (i + 3 < hw) {
+      float4 a = make_float4(0, 0, 0, 0);
+      for (int f = 0; f < nframes; ++f) {
+        const float4 v = *reinterpret_cast<const float4*>(frames + (int64_t)f * hw + i);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+      *reinterpret_cast<float4*>(sum + i) = a;
+    } else {
+      for (int64_t j = i; j < hw; ++j) {
+        float a = 0;
+        for (int f = 0; f < nframes; ++f) a += frames[(int64_t)f * hw + j];
+        sum[j] = a;
+      }
+    }
+  }
+}
+
+extern "C" {
+
+int mc_abi_version(void) { return MCORR_ABI_VERSION; }
+
+int mc_circle_mask(float* mask, int* halfw, int h, int w, float radius, float smoothing_radius,
+                   void* stream) {
+  if (!mask || !halfw || h < 1 || w < 1 || !(radius >= 0.f) || !(smoothing_radius >= 0.f))
+    return MC_ERR_ARG;
+  hipLaunchKernelGGL(mask_halfwidth, dim3((h + 63) / 64), dim3(64), 0, (hipStream_t)stream, halfw,
+                     h, w, radius);
+  hipLaunchKernelGGL(mask_fill, dim3((w + 255) / 256, h), dim3(256), 0, (hipStream_t)stream, mask,
+                     halfw, h, w, radius, smoothing_radius);
+  return mc_check_launch();
+}
+
+int mc_xc_filter(float* filt, const mc_xc_geom* q, float low, float high, float b_factor,
+                 float pixel_size, void* stream) {
+  if (!filt || !q || q->nkx < 1 || q->kyp + q->kyn < 1 || !(pixel_size > 0.f)) return MC_ERR_ARG;
+  const int n = q->nkx * (q->kyp + q->kyn);
+  hipLaunchKernelGGL(xc_filter_fill, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     filt, q->W, q->H, q->nkx, q->kyp, q->kyn, low, high, b_factor, pixel_size);
+  return mc_check_launch();
+}
+
+int mc_central_box_stats(const float* stack, int t, int h, int w, int hl, int hu, int wl, int wu,
+                         double* acc, float* out3, void* stream) {
+  if (!stack || !acc || !out3 || t < 1 || hl < 0 || hu > h || wl < 0 || wu > w || hl >= hu ||
+      wl >= wu)
+    return MC_ERR_ARG;
+  hipError_t e = hipMemsetAsync(acc, 0, 2 * sizeof(double), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  int chunks = (hu - hl + 15) / 16;
+  if (chunks > 256) chunks = 256;
+  hipLaunchKernelGGL(box_stats_partial, dim3(chunks, t), dim3(256), 0, (hipStream_t)stream, stack,
+                     h, w, hl, hu, wl, wu, acc);
+  const double count = (double)t * (hu - hl) * (wu - wl);
+  hipLaunchKernelGGL(box_stats_final, dim3(1), dim3(1), 0, (hipStream_t)stream, acc, count, out3);
+  return mc_check_launch();
+}
+
+int mc_normalize(const float* src, float* dst, int64_t n, const float* mean_rstd, void* stream) {
+  if (!src || !dst || !mean_rstd || n < 1) return MC_ERR_ARG;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     src, dst, n, mean_rstd);
+  return mc_check_launch();
+}
+
+int mc_sum_frames(const float* frames, int nframes, int64_t hw, float* sum, void* stream) {
+  if (!frames || !sum || nframes < 1 || hw < 1 || (hw & 3)) return MC_ERR_ARG;
+  int64_t blocks = (hw / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(sum_frames_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     frames, nframes, hw, sum);
+  return mc_check_launch();
+}
+
+}  // extern "C"

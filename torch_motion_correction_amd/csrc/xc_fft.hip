@@ -1,0 +1,517 @@
+// Pruned, separable 2-D real FFT engine with fused prologues/epilogues for the
+// cross-correlation shift search (reference: estimate_motion_xc.py:76-123 for whole
+// frames, :338-355 for patches).
+//
+// The reference materialises full spectra and full correlation maps.  Here the
+// binary band-pass (utils.py:104-112) and the finite support of the circular mask
+// (xc.py:69-74) are exploited exactly: spectrum bins the band-pass zeroes are never
+// produced (only nkx columns and kyp+kyn rows are kept) and image rows/columns the
+// mask zeroes are never read.  Zero contributions are skipped, nothing is
+// approximated.
+//
+//   K1 xc_rows_fwd   rows:  gather + (x-mean)*rstd*mask^e -> real FFT(W) -> first nkx bins
+//                           -> T1[job][kx][ysupport]            (transposed via LDS)
+//   K2 xc_cols_fwd   cols:  T1 column -> FFT(H) -> kept ky rows * filter -> S[job][kx][kyi]
+//   K3 xc_cols_inv   cols:  conj(S_ref)*S_cur -> inverse FFT(H) -> T2[pair][kx][y]
+//   K4 xc_rows_inv   rows:  T2 rows -> inverse real FFT(W) -> fused arg-max | store
+//   K5 xc_peak_final       reduce K4's per-workgroup candidates, decode wrap-around
+//   K6 xc_peak_nbhd        re-evaluate rows y-1,y,y+1 of one map for the parabola fit
+#include "mc_fft.h"
+#include "mcorr.h"
+
+struct XcGeom {
+  int W, H;      // transform size (powers of two)
+  int nkx;       // kept rfft columns [0, nkx)
+  int kyp, kyn;  // kept ky rows [0, kyp) and [H-kyn, H); nky = kyp + kyn
+  int y0, ny;    // rows [y0, y0+ny) of the window can be non-zero (ny % RG == 0)
+  int x0, x1;    // columns [x0, x1) can be non-zero (both even)
+  int RG;        // rows per workgroup in K1/K4
+};
+
+// ------------------------------------------------------------------ K1: rows forward
+template <int LOGN>
+__global__ __launch_bounds__(MC_WG) void xc_rows_fwd(
+    const float* __restrict__ src, const int64_t* __restrict__ job_off, int64_t row_stride,
+    const int* __restrict__ job_expo, const float* __restrict__ mask,
+    const float* __restrict__ mean_rstd, cfloat* __restrict__ T1,
+    const cfloat* __restrict__ tw_row, XcGeom g) {
+  constexpr int N = 1 << LOGN;  // complex length = W/2
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cfloat* line = reinterpret_cast<cfloat*>(smem);
+  cfloat* stg = line + lds_len(N);
+  const int tid = threadIdx.x;
+  const int job = blockIdx.y;
+  const int grp = blockIdx.x;
+  const int RG = g.RG;
+  const float mean = mean_rstd ? mean_rstd[0] : 0.f;
+  const float rstd = mean_rstd ? mean_rstd[1] : 1.f;
+  const int expo = job_expo ? job_expo[job] : (mask ? 1 : 0);
+  const float* base = src + job_off[job];
+
+  for (int r = 0; r < RG; ++r) {
+    const int y = g.y0 + grp * RG + r;
+    const float* row = base + (int64_t)y * row_stride;
+    const float* mrow = mask ? mask + (int64_t)y * g.W : nullptr;
+    auto load = [&](int n) {
+      const int x = 2 * n;
+      cfloat v = cmake(0.f, 0.f);
+      if (x >= g.x0 && x < g.x1) {
+        v.x = (row[x] - mean) * rstd;
+        v.y = (row[x + 1] - mean) * rstd;
+        if (expo > 0) {
+          const float m0 = mrow[x], m1 = mrow[x + 1];
+          for (int e = 0; e < expo; ++e) {
+            v.x *= m0;
+            v.y *= m1;
+          }
+        }
+      }
+      return v;
+    };
+    auto store = [&](int i, cfloat v) { line[lpad(i)] = v; };
+    wg_fft<N, -1>(line, tid, tw_row, 2, load, store);
+    __syncthreads();
+    // real-FFT unpack: X[k] = (Z[k] + conj(Z[N-k]))/2 - i/2 * w^k * (Z[k] - conj(Z[N-k]))
+    for (int k = tid; k < g.nkx; k += MC_WG) {
+      const cfloat zk = line[lpad(k & (N - 1))];
+      const cfloat zm = cconj(line[lpad((N - k) & (N - 1))]);
+      const cfloat s = cadd(zk, zm), d = csub(zk, zm);
+      const cfloat w = (k < N) ? tw_row[k] : cmake(-1.f, 0.f);
+      const cfloat wd = cmul(w, d);  // -i*wd = (wd.y, -wd.x)
+      stg[k * (RG + 1) + r] = cmake(0.5f * (s.x + wd.y), 0.5f * (s.y - wd.x));
+    }
+    __syncthreads();
+  }
+  cfloat* out = T1 + (int64_t)job * g.nkx * g.ny + (int64_t)grp * RG;
+  for (int i = tid; i < g.nkx * RG; i += MC_WG) {
+    const int kx = i / RG, r = i - kx * RG;
+    out[(int64_t)kx * g.ny + r] = stg[kx * (RG + 1) + r];
+  }
+}
+
+// ------------------------------------------------------------------ K2: columns forward
+template <int LOGH>
+__global__ __launch_bounds__(MC_WG) void xc_cols_fwd(const cfloat* __restrict__ T1,
+                                                     const float* __restrict__ filt,
+                                                     cfloat* __restrict__ S,
+                                                     const cfloat* __restrict__ tw_col, XcGeom g) {
+  constexpr int H = 1 << LOGH;
+  __shared__ __attribute__((aligned(16))) cfloat line[lds_len(H)];
+  const int tid = threadIdx.x;
+  const int kx = blockIdx.x, job = blockIdx.y;
+  const cfloat* col = T1 + ((int64_t)job * g.nkx + kx) * g.ny;
+  const int nky = g.kyp + g.kyn;
+  cfloat* out = S + ((int64_t)job * g.nkx + kx) * nky;
+  const float* f = filt ? filt + (int64_t)kx * nky : nullptr;
+  auto load = [&](int y) {
+    const int yy = y - g.y0;
+    return (yy >= 0 && yy < g.ny) ? col[yy] : cmake(0.f, 0.f);
+  };
+  auto store = [&](int ky, cfloat v) {
+    int kyi = -1;
+    if (ky < g.kyp) kyi = ky;
+    else if (ky >= H - g.kyn) kyi = ky - (H - g.kyn) + g.kyp;
+    if (kyi >= 0) out[kyi] = f ? cscale(v, f[kyi]) : v;
+  };
+  wg_fft<H, -1>(line, tid, tw_col, 1, load, store);
+}
+
+// ------------------------------------------------------------------ K3: columns inverse
+// pair p: cur spectrum index cur_idx[p] in S_cur, ref spectrum index ref_idx[p] in S_ref.
+// MODE 0: conj(ref)*cur (cross-correlation); MODE 1: cur * phase ramp (Fourier shift,
+// correct_motion.py:488-494) -- phase computed in K3 from shifts[p] = (sy, sx).
+template <int LOGH, int MODE>
+__global__ __launch_bounds__(MC_WG) void xc_cols_inv(
+    const cfloat* __restrict__ S_cur, const int* __restrict__ cur_idx,
+    const cfloat* __restrict__ S_ref, const int* __restrict__ ref_idx,
+    const float* __restrict__ shifts, cfloat* __restrict__ T2, const cfloat* __restrict__ tw_col,
+    float scale, XcGeom g) {
+  constexpr int H = 1 << LOGH;
+  __shared__ __attribute__((aligned(16))) cfloat line[lds_len(H)];
+  const int tid = threadIdx.x;
+  const int kx = blockIdx.x, p = blockIdx.y;
+  const int nky = g.kyp + g.kyn;
+  const cfloat* cur = S_cur + ((int64_t)cur_idx[p] * g.nkx + kx) * nky;
+  const cfloat* ref = MODE == 0 ? S_ref + ((int64_t)ref_idx[p] * g.nkx + kx) * nky : nullptr;
+  cfloat* out = T2 + ((int64_t)p * g.nkx + kx) * H;
+  float sy = 0.f, sx = 0.f, fx = 0.f;
+  if (MODE == 1) {
+    sy = shifts[2 * p];
+    sx = shifts[2 * p + 1];
+    fx = (float)kx / (float)g.W;  // rfftfreq
+  }
+  auto load = [&](int ky) {
+    int kyi = -1;
+    if (ky < g.kyp) kyi = ky;
+    else if (ky >= H - g.kyn) kyi = ky - (H - g.kyn) + g.kyp;
+    if (kyi < 0) return cmake(0.f, 0.f);
+    cfloat v;
+    if (MODE == 0) {
+      v = cmulc(ref[kyi], cur[kyi]);
+    } else {
+      // torch.fft.fftfreq: k/H for k < (H+1)/2 else (k-H)/H; angle = sum(-2*pi*f*s)
+      const int kk = (ky < (H + 1) / 2) ? ky : ky - H;
+      const float fy = (float)kk / (float)H;
+      const float m2pi = -6.283185307179586f;
+      const float ang = (m2pi * fy) * sy + (m2pi * fx) * sx;
+      float sn, cs;
+      sincosf(ang, &sn, &cs);
+      v = cmul(cur[kyi], cmake(cs, sn));
+    }
+    return cscale(v, scale);
+  };
+  auto store = [&](int y, cfloat v) { out[y] = v; };
+  wg_fft<H, +1>(line, tid, tw_col, 1, load, store);
+}
+
+// ------------------------------------------------------------------ K4: rows inverse
+struct PeakCand {
+  float v;
+  int idx;
+};
+__device__ __forceinline__ void cand_merge(float& bv, int& bi, float v, int i) {
+  if (v > bv || (v == bv && i < bi)) {
+    bv = v;
+    bi = i;
+  }
+}
+
+// EPI 0: arg-max over the whole map (partials per workgroup); EPI 1: store real rows.
+template <int LOGN, int EPI>
+__global__ __launch_bounds__(MC_WG) void xc_rows_inv(const cfloat* __restrict__ T2,
+                                                     float* __restrict__ part_val,
+                                                     int* __restrict__ part_idx,
+                                                     float* __restrict__ out_real,
+                                                     const int64_t* __restrict__ out_off,
+                                                     int64_t out_stride,
+                                                     const cfloat* __restrict__ tw_row, XcGeom g) {
+  constexpr int N = 1 << LOGN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cfloat* line = reinterpret_cast<cfloat*>(smem);
+  cfloat* stg = line + lds_len(N);
+  const int tid = threadIdx.x;
+  const int p = blockIdx.y, grp = blockIdx.x;
+  const int RG = g.RG;
+  const int ngrp = gridDim.x;
+  const cfloat* in = T2 + (int64_t)p * g.nkx * g.H + (int64_t)grp * RG;
+  for (int i = tid; i < g.nkx * RG; i += MC_WG) {
+    const int kx = i / RG, r = i - kx * RG;
+    stg[kx * (RG + 1) + r] = in[(int64_t)kx * g.H + r];
+  }
+  __syncthreads();
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int r = 0; r < RG; ++r) {
+    const int y = grp * RG + r;
+    // c2r pack: Z[k] = (X[k] + conj(X[N-k])) + i * conj(w^k) * (X[k] - conj(X[N-k]))
+    auto load = [&](int k) {
+      const int km = N - k;  // in [1, N]
+      cfloat xk = (k < g.nkx) ? stg[k * (RG + 1) + r] : cmake(0.f, 0.f);
+      cfloat xm = (km < g.nkx) ? cconj(stg[km * (RG + 1) + r]) : cmake(0.f, 0.f);
+      if (k == 0) {  // c2r ignores the imaginary part of the DC and Nyquist bins (pocketfft)
+        xk.y = 0.f;
+        xm.y = 0.f;
+      }
+      const cfloat s = cadd(xk, xm), d = csub(xk, xm);
+      cfloat w = tw_row[k];
+      w.y = -w.y;
+      const cfloat wd = cmul(w, d);  // i*wd = (-wd.y, wd.x)
+      return cmake(s.x - wd.y, s.y + wd.x);
+    };
+    if constexpr (EPI == 0) {
+      auto store = [&](int n, cfloat v) {
+        const int flat = y * g.W + 2 * n;
+        cand_merge(bv, bi, v.x, flat);
+        cand_merge(bv, bi, v.y, flat + 1);
+      };
+      wg_fft<N, +1>(line, tid, tw_row, 2, load, store);
+    } else {
+      float* orow = out_real + out_off[p] + (int64_t)y * out_stride;
+      auto store = [&](int n, cfloat v) {
+        orow[2 * n] = v.x;
+        orow[2 * n + 1] = v.y;
+      };
+      wg_fft<N, +1>(line, tid, tw_row, 2, load, store);
+    }
+    __syncthreads();  // line is reused by the next row
+  }
+  if constexpr (EPI == 0) {
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_down(bv, off);
+      const int oi = __shfl_down(bi, off);
+      cand_merge(bv, bi, ov, oi);
+    }
+    __shared__ float wv[MC_WG / 64];
+    __shared__ int wi[MC_WG / 64];
+    if ((tid & 63) == 0) {
+      wv[tid >> 6] = bv;
+      wi[tid >> 6] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < MC_WG / 64; ++w) cand_merge(bv, bi, wv[w], wi[w]);
+      part_val[(int64_t)p * ngrp + grp] = bv;
+      part_idx[(int64_t)p * ngrp + grp] = bi;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ K5: final peak
+// peaks[p] = flat index of the first maximum; shifts[p] = wrapped (y, x) as float
+// (xc.py:116-121: p if p <= n//2 else p - n).
+__global__ void xc_peak_final(const float* __restrict__ part_val, const int* __restrict__ part_idx,
+                              int ngrp, int H, int W, int* __restrict__ peaks,
+                              float* __restrict__ shifts) {
+  const int p = blockIdx.x;
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < ngrp; i += blockDim.x)
+    cand_merge(bv, bi, part_val[(int64_t)p * ngrp + i], part_idx[(int64_t)p * ngrp + i]);
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_down(bv, off);
+    const int oi = __shfl_down(bi, off);
+    cand_merge(bv, bi, ov, oi);
+  }
+  if (threadIdx.x == 0) {
+    if (bi == 0x7fffffff) bi = 0;
+    peaks[p] = bi;
+    const int py = bi / W, px = bi - py * W;
+    shifts[2 * p] = (float)(py <= H / 2 ? py : py - H);
+    shifts[2 * p + 1] = (float)(px <= W / 2 ? px : px - W);
+  }
+}
+
+// ------------------------------------------------------------------ K6: neighbourhood
+// nb[p][dy][dx] (3x3 floats) = correlation values around peaks[p], produced by the
+// same inverse-row arithmetic as K4 so the values are the ones the arg-max saw.
+// Entries outside the map are NaN.
+template <int LOGN>
+__global__ __launch_bounds__(MC_WG) void xc_peak_nbhd(const cfloat* __restrict__ T2,
+                                                      const int* __restrict__ peaks,
+                                                      float* __restrict__ nb,
+                                                      const cfloat* __restrict__ tw_row, XcGeom g) {
+  constexpr int N = 1 << LOGN;
+  __shared__ __attribute__((aligned(16))) cfloat line[lds_len(N)];
+  const int tid = threadIdx.x;
+  const int p = blockIdx.y, dy = (int)blockIdx.x - 1;
+  const int pk = peaks[p];
+  const int py = pk / g.W, px = pk - py * g.W;
+  const int y = py + dy;
+  float* o = nb + (int64_t)p * 9 + (dy + 1) * 3;
+  if (y < 0 || y >= g.H) {
+    if (tid < 3) o[tid] = __builtin_nanf("");
+    return;
+  }
+  const cfloat* in = T2 + (int64_t)p * g.nkx * g.H + y;
+  auto X = [&](int k) { return in[(int64_t)k * g.H]; };
+  auto load = [&](int k) {
+    const int km = N - k;
+    cfloat xk = (k < g.nkx) ? X(k) : cmake(0.f, 0.f);
+    cfloat xm = (km < g.nkx) ? cconj(X(km)) : cmake(0.f, 0.f);
+    if (k == 0) {
+      xk.y = 0.f;
+      xm.y = 0.f;
+    }
+    const cfloat s = cadd(xk, xm), d = csub(xk, xm);
+    cfloat w = tw_row[k];
+    w.y = -w.y;
+    const cfloat wd = cmul(w, d);
+    return cmake(s.x - wd.y, s.y + wd.x);
+  };
+  auto store = [&](int n, cfloat v) { line[lpad(n)] = v; };
+  wg_fft<N, +1>(line, tid, tw_row, 2, load, store);
+  __syncthreads();
+  if (tid < 3) {
+    const int x = px + tid - 1;
+    float v = __builtin_nanf("");
+    if (x >= 0 && x < g.W) {
+      const cfloat z = line[lpad(x >> 1)];
+      v = (x & 1) ? z.y : z.x;
+    }
+    o[tid] = v;
+  }
+}
+
+// ------------------------------------------------------------------ host dispatch
+#define MC_DISPATCH_CASE(V, ...) \
+  case V: {                      \
+    constexpr int L = V;         \
+    __VA_ARGS__;                 \
+  } break;
+#define MC_DISPATCH_LOG(LOGV, ...)          \
+  switch (LOGV) {                           \
+    MC_DISPATCH_CASE(4, __VA_ARGS__)        \
+    MC_DISPATCH_CASE(5, __VA_ARGS__)        \
+    MC_DISPATCH_CASE(6, __VA_ARGS__)        \
+    MC_DISPATCH_CASE(7, __VA_ARGS__)        \
+    MC_DISPATCH_CASE(8, __VA_ARGS__)        \
+    MC_DISPATCH_CASE(9, __VA_ARGS__)        \
+    MC_DISPATCH_CASE(10, __VA_ARGS__)       \
+    MC_DISPATCH_CASE(11, __VA_ARGS__)       \
+    MC_DISPATCH_CASE(12, __VA_ARGS__)       \
+    default:                                \
+      return MC_ERR_UNSUPPORTED;            \
+  }
+
+static int geom_from(const mc_xc_geom* q, XcGeom* g) {
+  if (!q) return MC_ERR_ARG;
+  if (!mc_is_pow2(q->W) || !mc_is_pow2(q->H) || q->W < 32 || q->W > 8192 || q->H < 16 ||
+      q->H > 4096)
+    return MC_ERR_UNSUPPORTED;
+  if (q->nkx < 1 || q->nkx > q->W / 2 + 1) return MC_ERR_ARG;
+  if (q->kyp < 0 || q->kyn < 0 || q->kyp + q->kyn < 1 || q->kyp + q->kyn > q->H) return MC_ERR_ARG;
+  if (q->RG < 1 || q->ny < 1 || q->ny % q->RG || q->H % q->RG) return MC_ERR_ARG;
+  if (q->y0 < 0 || q->y0 + q->ny > q->H) return MC_ERR_ARG;
+  if (q->x0 < 0 || q->x1 > q->W || (q->x0 & 1) || (q->x1 & 1) || q->x0 >= q->x1) return MC_ERR_ARG;
+  g->W = q->W; g->H = q->H; g->nkx = q->nkx; g->kyp = q->kyp; g->kyn = q->kyn;
+  g->y0 = q->y0; g->ny = q->ny; g->x0 = q->x0; g->x1 = q->x1; g->RG = q->RG;
+  return MC_OK;
+}
+
+static size_t rows_lds_bytes(int N, const XcGeom& g) {
+  return sizeof(cfloat) * ((size_t)lds_len(N) + (size_t)g.nkx * (g.RG + 1));
+}
+
+extern "C" {
+
+int mc_xc_rows_lds_bytes(const mc_xc_geom* q) {
+  XcGeom g;
+  int rc = geom_from(q, &g);
+  if (rc) return rc;
+  return (int)rows_lds_bytes(g.W / 2, g);
+}
+
+int mc_xc_rows_forward(const float* src, const int64_t* job_off, int64_t row_stride,
+                       const int* job_expo, const float* mask, const float* mean_rstd,
+                       void* T1, const void* tw_row, int njobs, const mc_xc_geom* q,
+                       void* stream) {
+  XcGeom g;
+  int rc = geom_from(q, &g);
+  if (rc) return rc;
+  if (!src || !job_off || !T1 || !tw_row || njobs < 1) return MC_ERR_ARG;
+  const int logn = mc_ilog2(g.W) - 1;
+  const size_t lds = rows_lds_bytes(g.W / 2, g);
+  if (lds > 160 * 1024) return MC_ERR_ARG;
+  dim3 grid(g.ny / g.RG, njobs);
+  MC_DISPATCH_LOG(logn, {
+    auto k = xc_rows_fwd<L>;
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, dim3(MC_WG), lds, (hipStream_t)stream, src, job_off, row_stride,
+                       job_expo, mask, mean_rstd, (cfloat*)T1, (const cfloat*)tw_row, g);
+  });
+  return mc_check_launch();
+}
+
+int mc_xc_cols_forward(const void* T1, const float* filt, void* S, const void* tw_col, int njobs,
+                       const mc_xc_geom* q, void* stream) {
+  XcGeom g;
+  int rc = geom_from(q, &g);
+  if (rc) return rc;
+  if (!T1 || !S || !tw_col || njobs < 1) return MC_ERR_ARG;
+  dim3 grid(g.nkx, njobs);
+  MC_DISPATCH_LOG(mc_ilog2(g.H), {
+    hipLaunchKernelGGL(xc_cols_fwd<L>, grid, dim3(MC_WG), 0, (hipStream_t)stream,
+                       (const cfloat*)T1, filt, (cfloat*)S, (const cfloat*)tw_col, g);
+  });
+  return mc_check_launch();
+}
+
+int mc_xc_cols_inverse(const void* S_cur, const int* cur_idx, const void* S_ref,
+                       const int* ref_idx, void* T2, const void* tw_col, float scale, int npairs,
+                       const mc_xc_geom* q, void* stream) {
+  XcGeom g;
+  int rc = geom_from(q, &g);
+  if (rc) return rc;
+  if (!S_cur || !cur_idx || !S_ref || !ref_idx || !T2 || !tw_col || npairs < 1) return MC_ERR_ARG;
+  dim3 grid(g.nkx, npairs);
+  MC_DISPATCH_LOG(mc_ilog2(g.H), {
+    hipLaunchKernelGGL((xc_cols_inv<L, 0>), grid, dim3(MC_WG), 0, (hipStream_t)stream,
+                       (const cfloat*)S_cur, cur_idx, (const cfloat*)S_ref, ref_idx,
+                       (const float*)nullptr, (cfloat*)T2, (const cfloat*)tw_col, scale, g);
+  });
+  return mc_check_launch();
+}
+
+int mc_fourier_shift_cols_inverse(const void* S, const int* idx, const float* shifts, void* T2,
+                                  const void* tw_col, float scale, int nframes,
+                                  const mc_xc_geom* q, void* stream) {
+  XcGeom g;
+  int rc = geom_from(q, &g);
+  if (rc) return rc;
+  if (!S || !idx || !shifts || !T2 || !tw_col || nframes < 1) return MC_ERR_ARG;
+  dim3 grid(g.nkx, nframes);
+  MC_DISPATCH_LOG(mc_ilog2(g.H), {
+    hipLaunchKernelGGL((xc_cols_inv<L, 1>), grid, dim3(MC_WG), 0, (hipStream_t)stream,
+                       (const cfloat*)S, idx, (const cfloat*)nullptr, (const int*)nullptr, shifts,
+                       (cfloat*)T2, (const cfloat*)tw_col, scale, g);
+  });
+  return mc_check_launch();
+}
+
+int mc_xc_rows_inverse_argmax(const void* T2, float* part_val, int* part_idx, int* peaks,
+                              float* shifts, const void* tw_row, int npairs, const mc_xc_geom* q,
+                              void* stream) {
+  XcGeom g;
+  int rc = geom_from(q, &g);
+  if (rc) return rc;
+  if (!T2 || !part_val || !part_idx || !peaks || !shifts || !tw_row || npairs < 1)
+    return MC_ERR_ARG;
+  const int logn = mc_ilog2(g.W) - 1;
+  const size_t lds = rows_lds_bytes(g.W / 2, g);
+  if (lds > 160 * 1024) return MC_ERR_ARG;
+  const int ngrp = g.H / g.RG;
+  dim3 grid(ngrp, npairs);
+  MC_DISPATCH_LOG(logn, {
+    auto k = xc_rows_inv<L, 0>;
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, dim3(MC_WG), lds, (hipStream_t)stream, (const cfloat*)T2, part_val,
+                       part_idx, (float*)nullptr, (const int64_t*)nullptr, (int64_t)0,
+                       (const cfloat*)tw_row, g);
+  });
+  rc = mc_check_launch();
+  if (rc) return rc;
+  hipLaunchKernelGGL(xc_peak_final, dim3(npairs), dim3(64), 0, (hipStream_t)stream, part_val,
+                     part_idx, ngrp, g.H, g.W, peaks, shifts);
+  return mc_check_launch();
+}
+
+int mc_xc_rows_inverse_store(const void* T2, float* out, const int64_t* out_off,
+                             int64_t out_stride, const void* tw_row, int nframes,
+                             const mc_xc_geom* q, void* stream) {
+  XcGeom g;
+  int rc = geom_from(q, &g);
+  if (rc) return rc;
+  if (!T2 || !out || !out_off || !tw_row || nframes < 1) return MC_ERR_ARG;
+  const int logn = mc_ilog2(g.W) - 1;
+  const size_t lds = rows_lds_bytes(g.W / 2, g);
+  if (lds > 160 * 1024) return MC_ERR_ARG;
+  dim3 grid(g.H / g.RG, nframes);
+  MC_DISPATCH_LOG(logn, {
+    auto k = xc_rows_inv<L, 1>;
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, dim3(MC_WG), lds, (hipStream_t)stream, (const cfloat*)T2,
+                       (float*)nullptr, (int*)nullptr, out, out_off, out_stride,
+                       (const cfloat*)tw_row, g);
+  });
+  return mc_check_launch();
+}
+
+int mc_xc_peak_neighbourhood(const void* T2, const int* peaks, float* nb, const void* tw_row,
+                             int npairs, const mc_xc_geom* q, void* stream) {
+  XcGeom g;
+  int rc = geom_from(q, &g);
+  if (rc) return rc;
+  if (!T2 || !peaks || !nb || !tw_row || npairs < 1) return MC_ERR_ARG;
+  const int logn = mc_ilog2(g.W) - 1;
+  dim3 grid(3, npairs);
+  MC_DISPATCH_LOG(logn, {
+    hipLaunchKernelGGL(xc_peak_nbhd<L>, grid, dim3(MC_WG), 0, (hipStream_t)stream,
+                       (const cfloat*)T2, peaks, nb, (const cfloat*)tw_row, g);
+  });
+  return mc_check_launch();
+}
+
+}  // extern "C"

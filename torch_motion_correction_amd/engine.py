@@ -1,0 +1,315 @@
+"""Device-side pipelines on top of libmcorr (all tensors already on the GPU).
+
+These functions only allocate buffers (torch caching allocator), build small index
+tables and enqueue libmcorr kernels on the current stream; they never synchronise.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, lattice, plan as planmod, spline
+from ._lib import check, ptr, stream_ptr
+
+WORKSPACE_BYTES = 2 << 30  # soft cap for one transposed intermediate (T1 / T2)
+
+
+def _i32(a, device):
+    return torch.as_tensor(np.asarray(a, dtype=np.int32), device=device)
+
+
+def _i64(a, device):
+    return torch.as_tensor(np.asarray(a, dtype=np.int64), device=device)
+
+
+# ------------------------------------------------------------------ statistics
+
+
+def central_box_stats(img: torch.Tensor, frac_low=0.25, frac_high=0.75) -> torch.Tensor:
+    """(mean, 1/std, std) of the central box over all frames (utils.py:49-84)."""
+    lib = _lib.load()
+    t, h, w = img.shape
+    hl, hu, wl, wu = int(frac_low * h), int(frac_high * h), int(frac_low * w), int(frac_high * w)
+    acc = torch.empty(2, dtype=torch.float64, device=img.device)
+    out3 = torch.empty(3, dtype=torch.float32, device=img.device)
+    check(lib.mc_central_box_stats(ptr(img), t, h, w, hl, hu, wl, wu, ptr(acc), ptr(out3),
+                                   stream_ptr(img.device)), "mc_central_box_stats")
+    return out3
+
+
+def normalize(img: torch.Tensor, stats: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    out = torch.empty_like(img)
+    check(lib.mc_normalize(ptr(img), ptr(out), img.numel(), ptr(stats), stream_ptr(img.device)),
+          "mc_normalize")
+    return out
+
+
+# ------------------------------------------------------------------ spectra
+
+
+def _forward_spectra(src, job_off, row_stride, job_expo, pl, stats, use_mask=True, use_filter=True):
+    """K1+K2 for a list of jobs -> S (njobs, nkx, nky, 2)."""
+    lib = _lib.load()
+    g, dev = pl.geom, src.device
+    njobs = int(job_off.numel())
+    S = torch.empty((njobs, g.nkx, g.nky, 2), dtype=torch.float32, device=dev)
+    per_job = g.nkx * g.ny * 8
+    chunk = max(1, min(njobs, WORKSPACE_BYTES // per_job))
+    T1 = torch.empty((chunk, g.nkx, g.ny, 2), dtype=torch.float32, device=dev)
+    st = stream_ptr(dev)
+    for a in range(0, njobs, chunk):
+        n = min(chunk, njobs - a)
+        off = job_off[a : a + n]
+        expo = None if job_expo is None else job_expo[a : a + n]
+        check(lib.mc_xc_rows_forward(ptr(src), ptr(off), row_stride, ptr(expo),
+                                     ptr(pl.mask) if use_mask else None, ptr(stats), ptr(T1),
+                                     ptr(pl.tw_row), n, g, st), "mc_xc_rows_forward")
+        check(lib.mc_xc_cols_forward(ptr(T1), ptr(pl.filt) if use_filter else None, ptr(S[a : a + n]),
+                                     ptr(pl.tw_col), n, g, st), "mc_xc_cols_forward")
+    return S
+
+
+def _peaks(S_cur, cur_idx, S_ref, ref_idx, pl, want_nbhd):
+    """K3+K4(+K6) for all pairs -> peaks (npairs,) int32, shifts (npairs,2), nb or None."""
+    lib = _lib.load()
+    g, dev = pl.geom, S_cur.device
+    npairs = int(cur_idx.numel())
+    peaks = torch.empty(npairs, dtype=torch.int32, device=dev)
+    shifts = torch.empty((npairs, 2), dtype=torch.float32, device=dev)
+    nb = torch.empty((npairs, 3, 3), dtype=torch.float32, device=dev) if want_nbhd else None
+    per_pair = g.nkx * g.H * 8
+    chunk = max(1, min(npairs, WORKSPACE_BYTES // per_pair))
+    T2 = torch.empty((chunk, g.nkx, g.H, 2), dtype=torch.float32, device=dev)
+    ngrp = g.H // g.RG
+    pv = torch.empty(chunk * ngrp, dtype=torch.float32, device=dev)
+    pi = torch.empty(chunk * ngrp, dtype=torch.int32, device=dev)
+    st = stream_ptr(dev)
+    scale = 1.0 / (g.H * g.W)
+    for a in range(0, npairs, chunk):
+        n = min(chunk, npairs - a)
+        check(lib.mc_xc_cols_inverse(ptr(S_cur), ptr(cur_idx[a : a + n]), ptr(S_ref),
+                                     ptr(ref_idx[a : a + n]), ptr(T2), ptr(pl.tw_col), scale, n, g,
+                                     st), "mc_xc_cols_inverse")
+        check(lib.mc_xc_rows_inverse_argmax(ptr(T2), ptr(pv), ptr(pi), ptr(peaks[a : a + n]),
+                                            ptr(shifts[a : a + n]), ptr(pl.tw_row), n, g, st),
+              "mc_xc_rows_inverse_argmax")
+        if want_nbhd:
+            check(lib.mc_xc_peak_neighbourhood(ptr(T2), ptr(peaks[a : a + n]), ptr(nb[a : a + n]),
+                                               ptr(pl.tw_row), n, g, st),
+                  "mc_xc_peak_neighbourhood")
+    return peaks, shifts, nb
+
+
+# ------------------------------------------------------------------ a1: global shifts
+
+
+def global_shifts(img, reference_frame, pixel_spacing, b_factor, frequency_range):
+    """Integer-pixel (t,2) shifts of every frame against `reference_frame`
+    (estimate_motion_xc.py:57-123); the reference frame's row is exactly zero."""
+    t, h, w = img.shape
+    dev = img.device
+    pl = planmod.get_xc_plan(h, w, pixel_spacing, b_factor, frequency_range, dev)
+    stats = central_box_stats(img)
+    job_off = torch.arange(t, device=dev, dtype=torch.int64) * (h * w)
+    S = _forward_spectra(img, job_off, w, None, pl, stats)
+    cur = [f for f in range(t) if f != reference_frame]
+    out = torch.zeros((t, 2), dtype=torch.float32, device=dev)
+    if not cur:
+        return out
+    cur_idx = _i32(cur, dev)
+    ref_idx = torch.full_like(cur_idx, reference_frame)
+    _, shifts, _ = _peaks(S, cur_idx, S, ref_idx, pl, want_nbhd=False)
+    out[cur_idx.long()] = shifts
+    return out
+
+
+# ------------------------------------------------------------------ a8: patch field
+
+
+def patch_field(img, stats, pixel_spacing, reference_frame, reference_strategy, b_factor,
+                frequency_range, patch_sidelength, sub_pixel_refinement, temporal_smoothing,
+                smoothing_window_size, field0, outlier_rejection, outlier_threshold):
+    """Per-patch shift field (2,t,gh,gw) in Angstrom, mean-subtracted, plus the patch
+    centres (estimate_motion_xc.py:250-411).  `img` is the (already pre-corrected)
+    stack; `stats` = central-box statistics to normalise with inside K1, or None when
+    `img` is already normalised.  `field0` = prior field resampled to (2,t,gh,gw) or None."""
+    lib = _lib.load()
+    t, h, w = img.shape
+    dev = img.device
+    p = int(patch_sidelength)
+    if reference_strategy not in ("middle_frame", "mean_except_current"):
+        raise ValueError(f"Unknown reference_strategy: {reference_strategy}")
+    if p > h or p > w:
+        raise ValueError(f"patch_sidelength {p} exceeds the frame size {h}x{w}")
+    pl = planmod.get_xc_plan(p, p, pixel_spacing, b_factor, frequency_range, dev)
+    g = pl.geom
+    cy, cx = lattice.patch_grid_centers(t, h, w, p)
+    gh, gw = len(cy), len(cx)
+    npatch = gh * gw
+    origin = ((cy[:, None] - p // 2) * w + (cx[None, :] - p // 2)).reshape(-1)  # (npatch,)
+    ref_expo, cur_expo, processed = lattice.mask_schedule(t, reference_strategy, reference_frame)
+    field = torch.zeros((2, t, gh, gw), dtype=torch.float32, device=dev) if field0 is None \
+        else field0.contiguous().clone()
+    st = stream_ptr(dev)
+
+    def jobs(frames, expos):
+        off = (np.asarray(frames, dtype=np.int64)[:, None] * (h * w) + origin[None, :]).reshape(-1)
+        ex = np.repeat(np.asarray(expos, dtype=np.int32), npatch)
+        return _i64(off, dev), _i32(ex, dev)
+
+    nproc = len(processed)
+    if nproc > 0:
+        if reference_strategy == "mean_except_current":
+            if t < 2:
+                raise ValueError("mean_except_current needs at least 2 frames")
+            if ref_expo.max() > 1 or cur_expo.max() > 0:
+                raise NotImplementedError("unexpected mask schedule")
+            off, ex1 = jobs(range(t), [1] * t)
+            U = _forward_spectra(img, off, w, ex1, pl, stats)
+            V = _forward_spectra(img, off, w, ex1 * 2, pl, stats)
+            table = torch.as_tensor((ref_expo == 1).astype(np.uint8), device=dev).contiguous()
+            REF = torch.empty_like(U)
+            check(lib.mc_xc_ref_mean_except_current(ptr(U), ptr(V), ptr(table), ptr(REF), t, npatch,
+                                                    g.nkx * g.nky, 1.0 / (t - 1), st),
+                  "mc_xc_ref_mean_except_current")
+            del V
+            S_cur, S_ref = U, REF
+        else:
+            off, ex = jobs(processed, [int(cur_expo[f]) + 1 for f in processed])
+            S_cur = _forward_spectra(img, off, w, ex, pl, stats)
+            off, ex = jobs([reference_frame] * nproc,
+                           [int(ref_expo[f, reference_frame]) + 1 for f in processed])
+            S_ref = _forward_spectra(img, off, w, ex, pl, stats)
+        pair_idx = torch.arange(nproc * npatch, device=dev, dtype=torch.int32)
+        peaks, _, nb = _peaks(S_cur, pair_idx, S_ref, pair_idx, pl, want_nbhd=sub_pixel_refinement)
+        flags = (1 if sub_pixel_refinement else 0) | (2 if outlier_rejection else 0)
+        check(lib.mc_field_accumulate(ptr(peaks), ptr(nb), ptr(_i32(processed, dev)), nproc, npatch,
+                                      p, t, float(pixel_spacing), float(outlier_threshold), flags,
+                                      ptr(field), st), "mc_field_accumulate")
+    window = 0
+    if temporal_smoothing:
+        window = int(smoothing_window_size)
+        if window % 2 == 0:
+            window += 1
+        window = min(window, t)
+        if window < 3:
+            window = 0
+        elif window % 2 == 0:
+            raise ValueError("If mode is 'interp', window_length must be odd (scipy savgol_filter)")
+    out = torch.empty_like(field)
+    check(lib.mc_field_smooth_center(ptr(field), ptr(out), t, npatch, window, 1, st),
+          "mc_field_smooth_center")
+    return out, lattice.centers_tensor(t, cy, cx)
+
+
+# ------------------------------------------------------------------ a14/a16: spline lattice
+
+
+def spline_lattice(field, ut, uy, ux, grid_type):
+    """Evaluate the (c,nt,nh,nw) spline grid `field` on the tensor-product lattice
+    ut x uy x ux (CPU float32 coordinate vectors in [0,1]) -> (c, NT, NY, NX)."""
+    lib = _lib.load()
+    dev = field.device
+    c, nt, nh, nw = field.shape
+    tabs = []
+    for n, u in ((nt, ut), (nh, uy), (nw, ux)):
+        idx, wts = spline.axis_taps(n, u, grid_type)
+        tabs.append((idx.to(dev), wts.to(dev), int(u.numel())))
+    out = torch.empty((c, tabs[0][2], tabs[1][2], tabs[2][2]), dtype=torch.float32, device=dev)
+    f = field.contiguous()
+    check(lib.mc_spline_lattice(ptr(f), c, nt, nh, nw, ptr(tabs[0][0]), ptr(tabs[0][1]), tabs[0][2],
+                                ptr(tabs[1][0]), ptr(tabs[1][1]), tabs[1][2], ptr(tabs[2][0]),
+                                ptr(tabs[2][1]), tabs[2][2], ptr(out), stream_ptr(dev)),
+          "mc_spline_lattice")
+    return out
+
+
+def frame_lattices(field, t, grid_type):
+    """(t, 2, 10gh, 10gw) Angstrom lattices, one per frame time linspace(0,1,t)
+    (correct_motion.py:57,67-72)."""
+    _, _, gh, gw = field.shape
+    lat = spline_lattice(field, torch.linspace(0, 1, steps=t), torch.linspace(0, 1, steps=10 * gh),
+                         torch.linspace(0, 1, steps=10 * gw), grid_type)
+    return lat.permute(1, 0, 2, 3).contiguous()
+
+
+# ------------------------------------------------------------------ a15/a17/a18: warp
+
+
+def warp(img, lattices, pixel_spacing, want_frames=True, want_sum=False):
+    """Resample every frame through its lattice; returns (frames or None, sum or None)."""
+    lib = _lib.load()
+    t, h, w = img.shape
+    dev = img.device
+    _, _, GH, GW = lattices.shape
+    nbytes = C.c_int64(0)
+    check(lib.mc_warp_scratch_bytes(t, h, w, GH, GW, C.byref(nbytes)), "mc_warp_scratch_bytes")
+    scratch = torch.empty((nbytes.value + 3) // 4, dtype=torch.float32, device=dev)
+    frames = torch.empty_like(img) if want_frames else None
+    total = torch.zeros((h, w), dtype=torch.float32, device=dev) if want_sum else None
+    check(lib.mc_warp_frames(ptr(img), t, h, w, ptr(lattices), GH, GW, float(pixel_spacing),
+                             ptr(scratch), ptr(frames), ptr(total), stream_ptr(dev)),
+          "mc_warp_frames")
+    return frames, total
+
+
+def pixel_shifts(lattice, h, w, pixel_spacing):
+    """(h,w,2) px shifts from one (2,GH,GW) Angstrom lattice (correct_motion.py:132-185)."""
+    lib = _lib.load()
+    dev = lattice.device
+    _, GH, GW = lattice.shape
+    nbytes = C.c_int64(0)
+    check(lib.mc_warp_scratch_bytes(1, h, w, GH, GW, C.byref(nbytes)), "mc_warp_scratch_bytes")
+    scratch = torch.empty((nbytes.value + 3) // 4, dtype=torch.float32, device=dev)
+    out = torch.empty((h, w, 2), dtype=torch.float32, device=dev)
+    check(lib.mc_pixel_shifts(ptr(lattice.contiguous()), GH, GW, h, w, float(pixel_spacing),
+                              ptr(scratch), ptr(out), stream_ptr(dev)), "mc_pixel_shifts")
+    return out
+
+
+# ------------------------------------------------------------------ a19: Fourier shift
+
+
+def fourier_shift(img, shifts):
+    """irfft2(rfft2(img) * exp(-2 pi i (fy sy + fx sx))) per frame; shifts (t,2) px
+    (correct_motion.py:484-496)."""
+    lib = _lib.load()
+    t, h, w = img.shape
+    dev = img.device
+    g = planmod.full_geometry(h, w)
+    tw_row, tw_col = planmod.get_twiddles(w, dev), planmod.get_twiddles(h, dev)
+    out = torch.empty_like(img)
+    per_frame = g.nkx * g.H * 8
+    chunk = max(1, min(t, WORKSPACE_BYTES // (2 * per_frame)))
+    T1 = torch.empty((chunk, g.nkx, g.ny, 2), dtype=torch.float32, device=dev)
+    S = torch.empty((chunk, g.nkx, g.nky, 2), dtype=torch.float32, device=dev)
+    idx = torch.arange(chunk, device=dev, dtype=torch.int32)
+    st = stream_ptr(dev)
+    shifts = shifts.to(dev, torch.float32).contiguous()
+    for a in range(0, t, chunk):
+        n = min(chunk, t - a)
+        off = torch.arange(a, a + n, device=dev, dtype=torch.int64) * (h * w)
+        check(lib.mc_xc_rows_forward(ptr(img), ptr(off), w, None, None, None, ptr(T1), ptr(tw_row), n,
+                                     g, st), "mc_xc_rows_forward")
+        check(lib.mc_xc_cols_forward(ptr(T1), None, ptr(S), ptr(tw_col), n, g, st),
+              "mc_xc_cols_forward")
+        # T1 is dead now and has the same footprint as T2: reuse it
+        check(lib.mc_fourier_shift_cols_inverse(ptr(S), ptr(idx), ptr(shifts[a : a + n]), ptr(T1),
+                                                ptr(tw_col), 1.0 / (h * w), n, g, st),
+              "mc_fourier_shift_cols_inverse")
+        check(lib.mc_xc_rows_inverse_store(ptr(T1), ptr(out), ptr(off), w, ptr(tw_row), n, g, st),
+              "mc_xc_rows_inverse_store")
+    return out
+
+
+def sum_frames(frames):
+    lib = _lib.load()
+    t, h, w = frames.shape
+    total = torch.empty((h, w), dtype=torch.float32, device=frames.device)
+    check(lib.mc_sum_frames(ptr(frames), t, h * w, ptr(total), stream_ptr(frames.device)),
+          "mc_sum_frames")
+    return total

@@ -1,0 +1,143 @@
+"""Host-side plans: pruned-transform geometry, twiddle tables, cached mask / filter.
+
+Everything here is small scalar/1-D host logic plus calls into libmcorr for the
+device-resident constants (mask via an exact EDT kernel, filter table).  Plans are
+cached per (device, shape, parameters) so steady-state calls launch no plan work
+(the reference rebuilds mask and filters on every call, estimate_motion_xc.py:69-95).
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import XcGeom, check, ptr, stream_ptr
+
+LDS_BUDGET = 80 * 1024  # bytes per workgroup for the row kernels (2 workgroups / CU)
+
+
+def _is_pow2(n: int) -> bool:
+    return n > 0 and (n & (n - 1)) == 0
+
+
+def band_limits(frequency_range, pixel_spacing):
+    """(low, high) in cycles/pixel as float32 scalars, computed with the same torch ops
+    as the reference's prepare_bandpass_filter (utils.py:97-101)."""
+    cuton, cutoff_max = torch.as_tensor(frequency_range).float()
+    cutoff = torch.lerp(cuton, cutoff_max, 1.0)
+    low = torch.as_tensor(1 / cuton, dtype=torch.float32) * pixel_spacing
+    high = torch.as_tensor(1 / cutoff, dtype=torch.float32) * pixel_spacing
+    return float(low), float(high)
+
+
+def xc_geometry(h: int, w: int, high: float, radius: float, smoothing: float) -> XcGeom:
+    """Pruning bounds for an (h, w) transform: which rfft columns / fft rows can be
+    non-zero under the band-pass `f <= high`, and which window rows/columns can be
+    non-zero under the soft disk mask.  All bounds are conservative supersets."""
+    if not (_is_pow2(h) and _is_pow2(w) and 32 <= w <= 8192 and 16 <= h <= 4096):
+        raise NotImplementedError(
+            f"transform size {h}x{w}: this build of libmcorr has power-of-two FFT lengths only "
+            "(32<=w<=8192, 16<=h<=4096)"
+        )
+    hi32 = np.float32(high)
+    fx = np.arange(w // 2 + 1, dtype=np.float32) * np.float32(1.0 / w)
+    nkx = int(np.nonzero(fx <= hi32)[0].max()) + 1 if (fx <= hi32).any() else 1
+    ky = np.arange(h)
+    kk = np.where(ky < (h + 1) // 2, ky, ky - h)
+    fy = np.abs(kk.astype(np.float32) * np.float32(1.0 / h))
+    keep = fy <= hi32
+    if not keep.any():
+        keep[0] = True
+    if keep.all():
+        kyp, kyn = h, 0
+    else:
+        kyp = int(np.argmin(keep))  # first False
+        kyn = int(np.argmin(keep[::-1]))  # trailing Trues
+    # mask support
+    cy, cx = h // 2, w // 2
+    reach = int(math.ceil(radius + smoothing)) + 2
+    y0, y1 = max(0, cy - reach), min(h, cy + reach + 1)
+    x0, x1 = max(0, cx - reach), min(w, cx + reach + 1)
+    x0 -= x0 & 1
+    x1 += x1 & 1
+    n_line = w // 2
+    rg = 16
+    while rg > 1 and 8 * (n_line + (n_line >> 4) + 1 + nkx * (rg + 1)) > LDS_BUDGET:
+        rg //= 2
+    rg = min(rg, h)
+    y0 -= y0 % rg
+    y1 = min(h, ((y1 + rg - 1) // rg) * rg)
+    return XcGeom(W=w, H=h, nkx=nkx, kyp=kyp, kyn=kyn, y0=y0, ny=y1 - y0, x0=x0, x1=x1, RG=rg)
+
+
+def full_geometry(h: int, w: int) -> XcGeom:
+    """No pruning at all (correct_motion_fast needs the full spectrum)."""
+    return xc_geometry(h, w, high=10.0, radius=float(max(h, w)), smoothing=0.0)
+
+
+def twiddles(n: int, device) -> torch.Tensor:
+    """exp(-2 pi i k / n), k in [0, n), complex64 stored as (n, 2) float32."""
+    k = np.arange(n, dtype=np.float64)
+    ang = -2.0 * np.pi * k / n
+    tw = np.stack([np.cos(ang), np.sin(ang)], axis=-1).astype(np.float32)
+    return torch.from_numpy(tw).to(device)
+
+
+@dataclass
+class XcPlan:
+    geom: XcGeom
+    mask: torch.Tensor  # (H, W) float32
+    filt: torch.Tensor  # (nkx, nky) float32
+    tw_row: torch.Tensor  # (W, 2)
+    tw_col: torch.Tensor  # (H, 2)
+    low: float
+    high: float
+
+
+_PLANS: dict = {}
+_TWIDDLES: dict = {}
+
+
+def get_twiddles(n: int, device) -> torch.Tensor:
+    key = (str(device), n)
+    if key not in _TWIDDLES:
+        _TWIDDLES[key] = twiddles(n, device)
+    return _TWIDDLES[key]
+
+
+def circle_mask(h: int, w: int, radius: float, smoothing: float, device) -> torch.Tensor:
+    lib = _lib.load()
+    mask = torch.empty((h, w), dtype=torch.float32, device=device)
+    halfw = torch.empty((h,), dtype=torch.int32, device=device)
+    check(lib.mc_circle_mask(ptr(mask), ptr(halfw), h, w, radius, smoothing, stream_ptr(device)),
+          "mc_circle_mask")
+    return mask
+
+
+def get_xc_plan(h: int, w: int, pixel_spacing: float, b_factor: float, frequency_range,
+                device) -> XcPlan:
+    """Plan for cross-correlating (h, w) windows: mask radius min(h,w)/4, soft edge
+    min(h,w)/8 (estimate_motion_xc.py:69-74 / :262-264)."""
+    key = (str(device), h, w, float(pixel_spacing), float(b_factor), tuple(map(float, frequency_range)))
+    if key in _PLANS:
+        return _PLANS[key]
+    lib = _lib.load()
+    low, high = band_limits(frequency_range, pixel_spacing)
+    radius, smoothing = min(h, w) / 4, min(h, w) / 8
+    geom = xc_geometry(h, w, high, radius, smoothing)
+    mask = circle_mask(h, w, radius, smoothing, device)
+    filt = torch.empty((geom.nkx, geom.nky), dtype=torch.float32, device=device)
+    check(lib.mc_xc_filter(ptr(filt), geom, low, high, float(b_factor), float(pixel_spacing),
+                           stream_ptr(device)), "mc_xc_filter")
+    plan = XcPlan(geom, mask, filt, get_twiddles(w, device), get_twiddles(h, device), low, high)
+    _PLANS[key] = plan
+    return plan
+
+
+def clear_plan_cache():
+    _PLANS.clear()
+    _TWIDDLES.clear()
