@@ -1,0 +1,184 @@
+"""Headline benchmark: frames/s motion-corrected on synthetic 40 x 4096 x 4096 fp32
+stacks (BASELINE.json configs[1]): estimate_global_motion -> correct_motion (+ fused
+frame sum), inputs and outputs resident in HBM.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU; movies are independent, so ranks never exchange data (weak
+scaling: one stack per rank per step).  torch.distributed (RCCL) is used only for the
+start/stop barrier and the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (warp_main):
+algorithmic bytes per launch = 8 B/pixel/frame x 40 frames (each frame read once and
+written once) over its mean duration, measured with HIP events on
+the launch stream around each launch inside the timed region.  `cpu_baseline` is the
+CPU oracle (a port of the reference's torch-CPU op sequence; the reference itself
+cannot be imported) on a bounded sample of the same workload.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+try:
+    METRIC = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+except Exception:
+    METRIC = "frames/sec motion-corrected, 40x4kx4k fp32 stack, 1/2/4/8 MI355X"
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def synth_stack(t, h, w, seed, device, noise=1.0, pad=64):
+    """SURVEY.md section 8d recipe on the device: white-noise texture cropped at integer
+    drift offsets + per-frame noise.  Returns (stack, dy, dx)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    base = torch.randn(h + 2 * pad, w + 2 * pad, generator=g, device=device)
+    dy = torch.round(torch.linspace(-6, 8, t)).long().tolist()
+    dx = torch.round(torch.linspace(5, -4, t)).long().tolist()
+    stack = torch.empty((t, h, w), dtype=torch.float32, device=device)
+    for f in range(t):
+        stack[f] = base[pad - dy[f] : pad - dy[f] + h, pad - dx[f] : pad - dx[f] + w]
+        stack[f] += noise * torch.randn(h, w, generator=g, device=device)
+    return stack, dy, dx
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=40)
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=6)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    import torch_motion_correction_amd as mc
+    from torch_motion_correction_amd import engine
+
+    t, h, w = args.frames, args.size, args.size
+    stack, dy, dx = synth_stack(t, h, w, 1234 + rank, dev)
+    ref = t // 2
+    expect = torch.tensor([[dy[f] - dy[ref], dx[f] - dx[ref]] for f in range(t)], dtype=torch.float32)
+
+    warp_events = []
+
+    def step(record):
+        shifts = engine.global_shifts(stack, ref, 1.0, 500.0, (300, 10))
+        field = mc.image_shifts_to_deformation_field(shifts, 1.0)
+        lat = engine.frame_lattices(field.contiguous(), t, "catmull_rom")
+        if record:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        frames, total = engine.warp(stack, lat, 1.0, want_frames=True, want_sum=True, rigid=True)
+        if record:
+            e1.record()
+            warp_events.append((e0, e1))
+        return shifts, frames, total
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    shifts = out[0].cpu()
+    shifts_ok = bool(torch.equal(shifts, expect))
+    warp_ms = sum(a.elapsed_time(b) for a, b in warp_events) / max(len(warp_events), 1)
+    alg_bytes = 8.0 * h * w * t  # read + write of every frame, once
+    achieved = alg_bytes / (warp_ms * 1e-3) / 1e9
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        import oracle
+
+        n = min(args.cpu_frames, t)
+        sample = stack[:n].cpu()
+        torch.set_num_threads(os.cpu_count() or 1)
+        c0 = time.perf_counter()
+        ofield = oracle.estimate_global_motion(sample, 1.0)
+        oracle.correct_motion(sample, ofield, 1.0).sum(0)
+        cpu_s = time.perf_counter() - c0
+        cpu = {
+            "value": n / cpu_s, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"first {n} frames of the same {h}x{w} stack: oracle estimate_global_motion + "
+                      f"correct_motion + sum, {cpu_s:.1f} s",
+        }
+
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "warp_traffic.json")
+    if os.path.exists(tp):
+        try:
+            traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        total_frames = world * t * args.steps
+        line = {
+            "metric": METRIC,
+            "value": total_frames / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{t}-frame {h}x{w} fp32 movie, global rigid shift estimate+correct "
+                            f"(estimate_global_motion -> correct_motion, frames + sum out), "
+                            f"1 stack per GPU per step",
+                "pixel_spacing": 1.0, "b_factor": 500, "frequency_range": [300, 10],
+                "shifts_match_ground_truth": shifts_ok,
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "warp_rigid", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "ms_per_launch": warp_ms, "algorithmic_bytes_per_launch": alg_bytes,
+            },
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -143,6 +143,14 @@ int mc_warp_frames(const float* frames, int nframes, int h, int w, const float* 
                    int GW, float pixel_spacing, float* scratch, float* out_frames, float* out_sum,
                    void* stream);
 
+/* Rigid special case of mc_warp_frames: a (2,nt,1,1) field gives each frame ONE shift,
+ * shifts_px[f] = (sy, sx) in pixels (device).  The coordinate chain is then separable
+ * and the resample is a regular 5x5 separable correlation (see warp.hip).  Same
+ * outputs/contract as mc_warp_frames.  scratch: mc_warp_rigid_scratch_bytes(). */
+int mc_warp_rigid_scratch_bytes(int nframes, int h, int w, int64_t* bytes /*host*/);
+int mc_warp_rigid(const float* frames, int nframes, int h, int w, const float* shifts_px,
+                  float* scratch, float* out_frames, float* out_sum, void* stream);
+
 /* get_pixel_shifts (correct_motion.py:132-185) for one (2,GH,GW) lattice: out (h,w,2)
  * shifts in px.  scratch: mc_warp_scratch_bytes(1,h,w,GH,GW). */
 int mc_pixel_shifts(const float* lattice, int GH, int GW, int h, int w, float pixel_spacing,

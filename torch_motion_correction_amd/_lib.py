@@ -48,6 +48,8 @@ SIGNATURES = {
     "mc_spline_lattice": [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, i32, vp, vp],
     "mc_warp_scratch_bytes": [i32, i32, i32, i32, i32, C.POINTER(C.c_int64)],
     "mc_warp_frames": [vp, i32, i32, i32, vp, i32, i32, f32, vp, vp, vp, vp],
+    "mc_warp_rigid_scratch_bytes": [i32, i32, i32, C.POINTER(C.c_int64)],
+    "mc_warp_rigid": [vp, i32, i32, i32, vp, vp, vp, vp, vp],
     "mc_pixel_shifts": [vp, i32, i32, i32, i32, f32, vp, vp, vp],
     "mc_fourier_shift_cols_inverse": [vp, vp, vp, vp, vp, f32, i32, GP, vp],
     "mc_xc_rows_inverse_store": [vp, vp, vp, i64, vp, i32, GP, vp],

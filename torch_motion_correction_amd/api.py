@@ -22,12 +22,17 @@ from . import engine
 from ._lib import require_gpu
 
 BUG_COMPATIBLE = True
+RIGID_FAST_PATH = True  # (2,nt,1,1) fields use the separable rigid warp kernel
 VERBOSE = False  # the reference prints progress lines; opt in with VERBOSE = True
 
 
 def _say(msg: str):
     if VERBOSE:
         print(msg)
+
+
+def _is_rigid(field: torch.Tensor) -> bool:
+    return tuple(field.shape[-2:]) == (1, 1)
 
 
 def _out_device(image: torch.Tensor, device):
@@ -180,7 +185,8 @@ def correct_motion(image, deformation_grid, pixel_spacing, grad=False, grid_type
     dev = require_gpu(out_dev)
     img = _stage(image, dev)
     lat = engine.frame_lattices(_stage(deformation_grid, dev), img.shape[0], grid_type)
-    frames, _ = engine.warp(img, lat, float(pixel_spacing), want_frames=True, want_sum=False)
+    frames, _ = engine.warp(img, lat, float(pixel_spacing), want_frames=True, want_sum=False,
+                            rigid=RIGID_FAST_PATH and _is_rigid(deformation_grid))
     return frames.to(out_dev)
 
 
@@ -193,7 +199,8 @@ def motion_correct_sum(image, deformation_grid, pixel_spacing, grid_type="catmul
     dev = require_gpu(out_dev)
     img = _stage(image, dev)
     lat = engine.frame_lattices(_stage(deformation_grid, dev), img.shape[0], grid_type)
-    frames, total = engine.warp(img, lat, float(pixel_spacing), want_frames=return_frames, want_sum=True)
+    frames, total = engine.warp(img, lat, float(pixel_spacing), want_frames=return_frames, want_sum=True,
+                                rigid=RIGID_FAST_PATH and _is_rigid(deformation_grid))
     return (total.to(out_dev), frames.to(out_dev)) if return_frames else total.to(out_dev)
 
 

@@ -16,6 +16,7 @@
 // contraction in this file): at coordinates ~4096 one ulp is 2.4e-4 px, which is
 // visible at the 1e-4 parity bar.
 #pragma clang fp contract(off)
+#include <stdlib.h>
 #include "mc_common.h"
 #include "mcorr.h"
 
@@ -82,9 +83,10 @@ __global__ void warp_etab(const float* __restrict__ lattice, int GH, int GW, int
   etab[(int64_t)row * w + x] = ((c.x * L[t.x] + c.y * L[t.y]) + c.z * L[t.z]) + c.w * L[t.w];
 }
 
-#define WARP_TX 32   // threads across (4 px each) -> 128 px
-#define WARP_TY 8    // thread rows; each thread does rows ty and ty+8 -> 16 rows
+#define WARP_TX 32   // threads across, 4 px each -> 128 px
+#define WARP_TY 8    // thread rows, 2 adjacent pixel rows each -> 16 rows
 #define WARP_PX 4
+#define WARP_ROWS 2
 
 struct WarpArgs {
   const float* frames;
@@ -98,132 +100,488 @@ struct WarpArgs {
   int tiles_x, tiles_y;
 };
 
-struct __attribute__((packed, aligned(4))) f4u {  // 16-byte load, dword aligned
-  float x, y, z, w;
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // dword-aligned 16-B load
+
+// Everything below that is not the coordinate chain may contract to FMA: ATen's own
+// vectorised kernel is built with FMA contraction and differs from any fixed op order
+// at the ulp level anyway (probed).
+#pragma clang fp contract(fast)
+__device__ __forceinline__ void cubic_coeffs_fast(float t, float c[4]) {
+  const float A = -0.75f;
+  float x = t + 1.f;
+  c[0] = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
+  x = t;
+  c[1] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+  x = 1.f - t;
+  c[2] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+  x = 2.f - t;
+  c[3] = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
+}
+__device__ __forceinline__ float dot4(const float4 c, float e0, float e1, float e2, float e3) {
+  return ((c.x * e0 + c.y * e1) + c.z * e2) + c.w * e3;
+}
+// 5-tap accumulate: taps 0..4 of a window, weights shifted by one when `up`
+__device__ __forceinline__ float dot5(const float wt[4], bool up, float v0, float v1, float v2,
+                                      float v3, float v4) {
+  const float a0 = up ? 0.f : wt[0];
+  const float a1 = up ? wt[0] : wt[1];
+  const float a2 = up ? wt[1] : wt[2];
+  const float a3 = up ? wt[2] : wt[3];
+  const float a4 = up ? wt[3] : 0.f;
+  return (((a0 * v0 + a1 * v1) + a2 * v2) + a3 * v3) + a4 * v4;
+}
+#pragma clang fp contract(off)
+
+struct TapWindow {   // rows by..by+4, cols bx..bx+7 of one frame
+  float v[5][8];
+  int by, bx;
+  bool valid;
 };
 
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ void window_load_row(TapWindow& win, int i, const float* fr, int w) {
+  const float* r = fr + (int64_t)(win.by + i) * w + win.bx;
+  const f4u lo = *reinterpret_cast<const f4u*>(r);
+  const f4u hi = *reinterpret_cast<const f4u*>(r + 4);
+  win.v[i][0] = lo.x; win.v[i][1] = lo.y; win.v[i][2] = lo.z; win.v[i][3] = lo.w;
+  win.v[i][4] = hi.x; win.v[i][5] = hi.y; win.v[i][6] = hi.z; win.v[i][7] = hi.w;
+}
 
-template <bool WRITE_FRAMES, bool WRITE_SUM>
+// Position the window at (by, bx); reuse rows when it only moved down by one.
+__device__ __forceinline__ void window_seek(TapWindow& win, int by, int bx, const float* fr, int w) {
+  if (win.valid && win.bx == bx && win.by == by) return;
+  if (win.valid && win.bx == bx && win.by + 1 == by) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) win.v[i][j] = win.v[i + 1][j];
+    win.by = by;
+    window_load_row(win, 4, fr, w);
+    return;
+  }
+  win.by = by;
+  win.bx = bx;
+  win.valid = true;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) window_load_row(win, i, fr, w);
+}
+
+template <bool UNIT_PS>
+__device__ __forceinline__ void warp_row(const WarpArgs& a, const float* fr, int y, int x0,
+                                         const float4 yc, const float4 Ey[4], const float4 Ex[4],
+                                         TapWindow& win, float res[WARP_PX]) {
+  const int h = a.h, w = a.w;
+  const float fh = (float)h, fw = (float)w;
+  float uy[WARP_PX], ux[WARP_PX], fy[WARP_PX], fx[WARP_PX];
+  bool inside[WARP_PX];
+  const float ey[4][4] = {{Ey[0].x, Ey[0].y, Ey[0].z, Ey[0].w}, {Ey[1].x, Ey[1].y, Ey[1].z, Ey[1].w},
+                          {Ey[2].x, Ey[2].y, Ey[2].z, Ey[2].w}, {Ey[3].x, Ey[3].y, Ey[3].z, Ey[3].w}};
+  const float ex[4][4] = {{Ex[0].x, Ex[0].y, Ex[0].z, Ex[0].w}, {Ex[1].x, Ex[1].y, Ex[1].z, Ex[1].w},
+                          {Ex[2].x, Ex[2].y, Ex[2].z, Ex[2].w}, {Ex[3].x, Ex[3].y, Ex[3].z, Ex[3].w}};
+  float fby = 3.0e38f, fbx = 3.0e38f;
+#pragma unroll
+  for (int k = 0; k < WARP_PX; ++k) {
+    float sy = dot4(yc, ey[0][k], ey[1][k], ey[2][k], ey[3][k]);
+    float sx = dot4(yc, ex[0][k], ex[1][k], ex[2][k], ex[3][k]);
+    if (!UNIT_PS) {
+      sy = sy / a.pixel_spacing;
+      sx = sx / a.pixel_spacing;
+    }
+    const float cy = (float)y + sy, cx = (float)(x0 + k) + sx;
+    inside[k] = (cy >= 0.f) && (cy <= fh - 1.f) && (cx >= 0.f) && (cx <= fw - 1.f);
+    uy[k] = grid_chain(cy, fh);
+    ux[k] = grid_chain(cx, fw);
+    fy[k] = floorf(uy[k]);
+    fx[k] = floorf(ux[k]);
+    fby = fminf(fby, fy[k]);
+    fbx = fminf(fbx, fx[k] - (float)k);
+  }
+  bool ok = (fby >= 1.f) && (fby + 3.f <= fh - 1.f) && (fbx >= 1.f) && (fbx + 6.f <= fw - 1.f);
+#pragma unroll
+  for (int k = 0; k < WARP_PX; ++k) {
+    const float dy = fy[k] - fby, dx = fx[k] - (float)k - fbx;
+    ok = ok && (dy == 0.f || dy == 1.f) && (dx == 0.f || dx == 1.f);
+  }
+  if (ok) {
+    window_seek(win, (int)fby - 1, (int)fbx - 1, fr, w);
+#pragma unroll
+    for (int k = 0; k < WARP_PX; ++k) {
+      float wy[4], wx[4];
+      cubic_coeffs_fast(uy[k] - fy[k], wy);
+      cubic_coeffs_fast(ux[k] - fx[k], wx);
+      const bool upy = fy[k] != fby, upx = (fx[k] - (float)k) != fbx;
+      float rowv[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+        rowv[i] = dot5(wx, upx, win.v[i][k], win.v[i][k + 1], win.v[i][k + 2], win.v[i][k + 3],
+                       win.v[i][k + 4]);
+      const float o = dot5(wy, upy, rowv[0], rowv[1], rowv[2], rowv[3], rowv[4]);
+      res[k] = inside[k] ? o : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < WARP_PX; ++k) {
+      float wy[4], wx[4];
+      cubic_coeffs_fast(uy[k] - fy[k], wy);
+      cubic_coeffs_fast(ux[k] - fx[k], wx);
+      // border padding: clip each tap coordinate (ATen clip_coordinates), in float first
+      // so that huge coordinates cannot overflow the int conversion
+      float rowv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float ty = fminf(fmaxf(fy[k] + (float)(i - 1), 0.f), fh - 1.f);
+        const float* r = fr + (int64_t)(int)ty * w;
+        float t4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          t4[j] = r[(int)fminf(fmaxf(fx[k] + (float)(j - 1), 0.f), fw - 1.f)];
+        rowv[i] = dot4(make_float4(wx[0], wx[1], wx[2], wx[3]), t4[0], t4[1], t4[2], t4[3]);
+      }
+      const float o = dot4(make_float4(wy[0], wy[1], wy[2], wy[3]), rowv[0], rowv[1], rowv[2], rowv[3]);
+      res[k] = inside[k] ? o : 0.f;
+    }
+  }
+}
+
+__device__ __forceinline__ void load_etab4(const float* E, int64_t rowstride, const int4 yt, int x0,
+                                           int w, float4 out[4]) {
+  const int rows[4] = {yt.x, yt.y, yt.z, yt.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float* p = E + (int64_t)rows[i] * rowstride + x0;
+    if (x0 + 3 < w && ((rowstride & 3) == 0)) {
+      out[i] = *reinterpret_cast<const float4*>(p);
+    } else {
+      out[i].x = p[0];
+      out[i].y = x0 + 1 < w ? p[1] : 0.f;
+      out[i].z = x0 + 2 < w ? p[2] : 0.f;
+      out[i].w = x0 + 3 < w ? p[3] : 0.f;
+    }
+  }
+}
+
+template <bool WRITE_FRAMES, bool WRITE_SUM, bool UNIT_PS>
 __global__ __launch_bounds__(WARP_TX* WARP_TY) void warp_main(WarpArgs a) {
   // XCD-aware tile order: blocks b, b+8, b+16.. share an XCD (round-robin dispatch);
   // give each XCD a contiguous band of tile rows so vertical halos hit its own L2.
   const int nt = a.tiles_x * a.tiles_y;
-  int b = blockIdx.x;
+  const int b = blockIdx.x;
   int tile = b;
   if ((nt & 7) == 0) tile = (b & 7) * (nt >> 3) + (b >> 3);
   const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
   const int x0 = txi * (WARP_TX * WARP_PX) + threadIdx.x * WARP_PX;
+  const int ya = tyi * (WARP_TY * WARP_ROWS) + threadIdx.y * WARP_ROWS;
   const int h = a.h, w = a.w;
-  const float fh = (float)h, fw = (float)w;
+  if (ya >= h || x0 >= w) return;
   const int64_t hw = (int64_t)h * w;
+  const bool two = (ya + 1 < h);
+  const int yb = two ? ya + 1 : ya;
+  const int4 yta = *reinterpret_cast<const int4*>(a.ytap + 4 * ya);
+  const float4 yca = *reinterpret_cast<const float4*>(a.ycoef + 4 * ya);
+  const int4 ytb = *reinterpret_cast<const int4*>(a.ytap + 4 * yb);
+  const float4 ycb = *reinterpret_cast<const float4*>(a.ycoef + 4 * yb);
+  const bool same = (yta.x == ytb.x) && (yta.y == ytb.y) && (yta.z == ytb.z) && (yta.w == ytb.w);
+  const bool full = (x0 + WARP_PX <= w);
+  float acc[WARP_ROWS][WARP_PX] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    const int y = tyi * (WARP_TY * 2) + half * WARP_TY + threadIdx.y;
-    if (y >= h || x0 >= w) continue;
-    const int4 yt = *reinterpret_cast<const int4*>(a.ytap + 4 * y);
-    const float4 yc = *reinterpret_cast<const float4*>(a.ycoef + 4 * y);
-    const bool full = (x0 + WARP_PX <= w);
-    float acc[WARP_PX] = {0.f, 0.f, 0.f, 0.f};
-
-    for (int f = 0; f < a.nframes; ++f) {
-      const float* fr = a.frames + (int64_t)f * hw;
-      const float* E = a.etab + (int64_t)f * 2 * a.GH * w;
-      float res[WARP_PX];
-      float uy[WARP_PX], ux[WARP_PX];
-      bool inside[WARP_PX];
-#pragma unroll
-      for (int k = 0; k < WARP_PX; ++k) {
-        const int x = x0 + k < w ? x0 + k : w - 1;
-        const float* Ey = E + x;
-        const float* Ex = E + (int64_t)a.GH * w + x;
-        float sy = ((yc.x * Ey[(int64_t)yt.x * w] + yc.y * Ey[(int64_t)yt.y * w]) +
-                    yc.z * Ey[(int64_t)yt.z * w]) + yc.w * Ey[(int64_t)yt.w * w];
-        float sx = ((yc.x * Ex[(int64_t)yt.x * w] + yc.y * Ex[(int64_t)yt.y * w]) +
-                    yc.z * Ex[(int64_t)yt.z * w]) + yc.w * Ex[(int64_t)yt.w * w];
-        sy = sy / a.pixel_spacing;
-        sx = sx / a.pixel_spacing;
-        const float cy = (float)y + sy, cx = (float)x + sx;
-        inside[k] = (cy >= 0.f) && (cy <= fh - 1.f) && (cx >= 0.f) && (cx <= fw - 1.f);
-        uy[k] = grid_chain(cy, fh);
-        ux[k] = grid_chain(cx, fw);
+  for (int f = 0; f < a.nframes; ++f) {
+    const float* fr = a.frames + (int64_t)f * hw;
+    const float* E = a.etab + (int64_t)f * 2 * a.GH * w;
+    float4 Ey[4], Ex[4];
+    load_etab4(E, w, yta, x0, w, Ey);
+    load_etab4(E + (int64_t)a.GH * w, w, yta, x0, w, Ex);
+    TapWindow win;
+    win.valid = false;
+    win.by = win.bx = 0;
+    float res[WARP_ROWS][WARP_PX];
+    warp_row<UNIT_PS>(a, fr, ya, x0, yca, Ey, Ex, win, res[0]);
+    if (two) {
+      if (!same) {
+        load_etab4(E, w, ytb, x0, w, Ey);
+        load_etab4(E + (int64_t)a.GH * w, w, ytb, x0, w, Ex);
       }
-      const float fy0 = floorf(uy[0]), fx0 = floorf(ux[0]);
-      const int iy0 = (int)fy0, ix0 = (int)fx0;
-      bool regular = full && iy0 >= 1 && iy0 + 2 <= h - 1 && ix0 >= 1 && ix0 + 6 <= w - 1;
+      warp_row<UNIT_PS>(a, fr, yb, x0, ycb, Ey, Ex, win, res[1]);
+    }
 #pragma unroll
-      for (int k = 1; k < WARP_PX; ++k)
-        regular = regular && (floorf(uy[k]) == fy0) && (floorf(ux[k]) == fx0 + (float)k);
-      if (regular) {
-        float v[4][8];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float* r = fr + (int64_t)(iy0 - 1 + i) * w + (ix0 - 1);
-          const f4u lo = *reinterpret_cast<const f4u*>(r);
-          const f4u hi = *reinterpret_cast<const f4u*>(r + 4);
-          v[i][0] = lo.x; v[i][1] = lo.y; v[i][2] = lo.z; v[i][3] = lo.w;
-          v[i][4] = hi.x; v[i][5] = hi.y; v[i][6] = hi.z; v[i][7] = hi.w;
-        }
-#pragma unroll
-        for (int k = 0; k < WARP_PX; ++k) {
-          float wy[4], wx[4];
-          cubic_coeffs(uy[k] - fy0, wy);
-          cubic_coeffs(ux[k] - (fx0 + (float)k), wx);
-          float rowv[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            rowv[i] = ((wx[0] * v[i][k] + wx[1] * v[i][k + 1]) + wx[2] * v[i][k + 2]) +
-                      wx[3] * v[i][k + 3];
-          const float o = ((wy[0] * rowv[0] + wy[1] * rowv[1]) + wy[2] * rowv[2]) + wy[3] * rowv[3];
-          res[k] = inside[k] ? o : 0.f;
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < WARP_PX; ++k) {
-          const float fy = floorf(uy[k]), fx = floorf(ux[k]);
-          float wy[4], wx[4];
-          cubic_coeffs(uy[k] - fy, wy);
-          cubic_coeffs(ux[k] - fx, wx);
-          // border padding: clip each tap coordinate (ATen clip_coordinates), in float
-          // first so that huge coordinates cannot overflow the int conversion
-          float rowv[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float ty = fminf(fmaxf(fy + (float)(i - 1), 0.f), fh - 1.f);
-            const float* r = fr + (int64_t)(int)ty * w;
-            float s = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float tx = fminf(fmaxf(fx + (float)(j - 1), 0.f), fw - 1.f);
-              const float term = wx[j] * r[(int)tx];
-              s = (j == 0) ? term : s + term;
-            }
-            rowv[i] = s;
-          }
-          const float o = ((wy[0] * rowv[0] + wy[1] * rowv[1]) + wy[2] * rowv[2]) + wy[3] * rowv[3];
-          res[k] = inside[k] ? o : 0.f;
-        }
-      }
+    for (int r = 0; r < WARP_ROWS; ++r) {
+      if (r == 1 && !two) break;
       if (WRITE_FRAMES) {
-        float* o = a.out_frames + (int64_t)f * hw + (int64_t)y * w + x0;
+        float* o = a.out_frames + (int64_t)f * hw + (int64_t)(ya + r) * w + x0;
         if (full && ((((uintptr_t)o) & 15) == 0)) {
-          *reinterpret_cast<float4*>(o) = make_float4(res[0], res[1], res[2], res[3]);
+          *reinterpret_cast<float4*>(o) = make_float4(res[r][0], res[r][1], res[r][2], res[r][3]);
         } else {
-          for (int k = 0; k < WARP_PX && x0 + k < w; ++k) o[k] = res[k];
+          for (int k = 0; k < WARP_PX && x0 + k < w; ++k) o[k] = res[r][k];
         }
       }
       if (WRITE_SUM) {
 #pragma unroll
-        for (int k = 0; k < WARP_PX; ++k) acc[k] += res[k];
+        for (int k = 0; k < WARP_PX; ++k) acc[r][k] += res[r][k];
       }
     }
-    if (WRITE_SUM) {
-      float* o = a.out_sum + (int64_t)y * w + x0;
-      for (int k = 0; k < WARP_PX && x0 + k < w; ++k) o[k] += acc[k];
+  }
+  if (WRITE_SUM) {
+    for (int r = 0; r < WARP_ROWS; ++r) {
+      if (r == 1 && !two) break;
+      float* o = a.out_sum + (int64_t)(ya + r) * w + x0;
+      for (int k = 0; k < WARP_PX && x0 + k < w; ++k) o[k] += acc[r][k];
     }
   }
 }
+
+// ------------------------------------------------------------------ rigid warp
+// A (2,nt,1,1) field gives every frame one shift (sy, sx) [px].  The coordinate chain
+// of sample_image_2d then depends on y alone (rows) and x alone (columns), so the
+// bicubic resample is a separable correlation whose 4 taps per axis sit at
+// floor(u)-1..floor(u)+2.  floor(u(p)) - p takes at most two adjacent values along an
+// axis (u = p + s up to fp32 rounding), so with S = min(floor(u(p)) - p) every output
+// uses the 5 input samples p+S-1 .. p+S+3 with the 4 weights placed at offset
+// d = floor(u(p)) - p - S in {0,1} (the fifth weight is an exact zero): same products,
+// same summation order as the 4-tap form, but a perfectly regular access pattern.
+// Rows/columns whose coordinate leaves [0,n-1] get all-zero weights (the reference
+// zeroes those samples).  The reference's own per-pixel shift is the bicubic upsample
+// of a constant lattice, i.e. s*(1 +- ~2e-6); here s is used as is.
+#define RIGID_LANES 64
+#define RIGID_WAVES 4
+#define RIGID_ROWS 8                                   // output rows per wave
+#ifndef RIGID_MINW
+#define RIGID_MINW 2
+#endif
+#define RIGID_TROWS (RIGID_WAVES * RIGID_ROWS + 4)     // input rows per tile (36)
+#define RIGID_QUADS (RIGID_LANES + 4)                  // float4 columns per tile row (68)
+#define RIGID_PLANE (RIGID_QUADS + 1)                  // plane stride in floats (odd: no conflicts)
+#define RIGID_RSTRIDE (4 * RIGID_PLANE)                // LDS floats per tile row
+#define RIGID_NQ (RIGID_TROWS * RIGID_QUADS)           // quads per tile (2448)
+#define RIGID_QPT ((RIGID_NQ + 255) / 256)             // quads per thread (10)
+
+// pass 0: S[f][axis] = min_p floor(u(p)) - p
+__global__ void rigid_base(const float* __restrict__ shifts, int nframes, int h, int w,
+                           int* __restrict__ S) {
+  const int f = blockIdx.y, axis = blockIdx.z;
+  const int n = axis == 0 ? h : w;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const float s = shifts[2 * f + axis];
+  const float u = grid_chain((float)p + s, (float)n);
+  const float d = floorf(u) - (float)p;
+  // clamp the (finite) offset so absurd shifts cannot overflow
+  const float lim = 3.0f * (float)n + 16.f;
+  const int di = (int)fminf(fmaxf(d, -lim), lim);
+  atomicMin(&S[2 * f + axis], di);
+}
+
+// pass 1: W[f][axis][k][p], k = 0..4
+__global__ void rigid_weights(const float* __restrict__ shifts, int nframes, int h, int w,
+                              const int* __restrict__ S, float* __restrict__ Wy,
+                              float* __restrict__ Wx) {
+  const int f = blockIdx.y, axis = blockIdx.z;
+  const int n = axis == 0 ? h : w;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const float s = shifts[2 * f + axis];
+  const float c = (float)p + s;
+  const bool inside = (c >= 0.f) && (c <= (float)n - 1.f);
+  const float u = grid_chain(c, (float)n);
+  const float fl = floorf(u);
+  float wt[4];
+  cubic_coeffs_fast(u - fl, wt);
+  const float lim = 3.0f * (float)n + 16.f;
+  const int d = (int)fminf(fmaxf(fl - (float)p, -lim), lim) - S[2 * f + axis];
+  float out[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  if (inside && d >= 0 && d <= 1) {
+    for (int k = 0; k < 4; ++k) out[k + d] = wt[k];
+  }
+  if (axis == 0) {
+    float* W = Wy + ((int64_t)f * n + p) * 5;  // [f][y][5]: a strip's weights are contiguous
+    for (int k = 0; k < 5; ++k) W[k] = out[k];
+  } else {
+    float* W = Wx + (int64_t)f * 5 * n;  // [f][5][x]: float4 per tap for 4 adjacent columns
+    for (int k = 0; k < 5; ++k) W[(int64_t)k * n + p] = out[k];
+  }
+}
+
+struct RigidArgs {
+  const float* frames;
+  int nframes, h, w;
+  const int* S;     // [f][2]
+  const float* Wy;  // [f][h][5]
+  const float* Wx;  // [f][5][w]
+  float* out_frames;
+  float* out_sum;
+  int tiles_x, tiles_y;
+  int frames_in_grid;  // 1: blockIdx.y selects the frame (no fused sum)
+};
+
+#pragma clang fp contract(fast)
+// Workgroup = 4 waves = tile of 256 x 32 output pixels.  Per frame the tile's 36 x 272
+// input window (row/column indices clipped to the image = border padding) is fetched
+// ONCE with 16-byte loads and parked in LDS de-interleaved by (column mod 4): the
+// window is misaligned by m = (x_tile + Sx - 1) mod 4 floats, and with four planes lane l
+// reads tap j at plane (m+j)&3, index l + ((m+j)>>2): consecutive lanes, consecutive
+// banks.  Loads for frame f+1 are in flight (registers) while frame f is computed.
+template <bool WRITE_FRAMES, bool WRITE_SUM>
+__global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES, RIGID_MINW) void warp_rigid(RigidArgs a) {
+  __shared__ float tileS[RIGID_TROWS * RIGID_RSTRIDE];
+  const int nt = a.tiles_x * a.tiles_y;
+  const int b = blockIdx.x;
+  int tile = b;
+  if ((nt & 7) == 0) tile = (b & 7) * (nt >> 3) + (b >> 3);  // one band of tile rows per XCD
+  const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
+  const int h = a.h, w = a.w;
+  const int lane = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int tid = wave * RIGID_LANES + lane;
+  const int xt = txi * (RIGID_LANES * 4);
+  const int yt = tyi * (RIGID_WAVES * RIGID_ROWS);
+  const int x0 = xt + lane * 4;
+  const int y0 = yt + wave * RIGID_ROWS;
+  const int64_t hw = (int64_t)h * w;
+  const bool full = (x0 + 4 <= w) && ((w & 3) == 0);
+  const bool wq = ((w & 3) == 0);
+  float acc[RIGID_ROWS][4];
+#pragma unroll
+  for (int r = 0; r < RIGID_ROWS; ++r)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[r][k] = 0.f;
+
+  const int f_lo = a.frames_in_grid ? (int)blockIdx.y : 0;
+  const int f_hi = a.frames_in_grid ? f_lo + 1 : a.nframes;
+
+  float4 pre[RIGID_QPT];
+  auto fetch = [&](int f) {  // issue the tile loads of frame f into `pre`
+    const float* fr = a.frames + (int64_t)f * hw;
+    const int Sy = a.S[2 * f], Sx = a.S[2 * f + 1];
+    const int cxt = xt + Sx - 1;
+    const int ax = cxt & ~3;  // aligned-down first column (two's complement: works for cxt < 0)
+    const bool fast = wq && ax >= 0 && ax + 4 * RIGID_QUADS <= w;
+#pragma unroll
+    for (int i = 0; i < RIGID_QPT; ++i) {
+      const int q = tid + i * 256;
+      if (q < RIGID_NQ) {
+        const int tr = q / RIGID_QUADS, qc = q - tr * RIGID_QUADS;
+        int r = yt + Sy - 1 + tr;
+        r = r < 0 ? 0 : (r > h - 1 ? h - 1 : r);
+        const float* row = fr + (int64_t)r * w;
+        const int c = ax + 4 * qc;
+        if (fast) {
+          pre[i] = *reinterpret_cast<const float4*>(row + c);
+        } else {
+          float e[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            int cc = c + k;
+            cc = cc < 0 ? 0 : (cc > w - 1 ? w - 1 : cc);
+            e[k] = row[cc];
+          }
+          pre[i] = make_float4(e[0], e[1], e[2], e[3]);
+        }
+      }
+    }
+  };
+  auto park = [&]() {  // registers -> LDS planes
+#pragma unroll
+    for (int i = 0; i < RIGID_QPT; ++i) {
+      const int q = tid + i * 256;
+      if (q < RIGID_NQ) {
+        const int tr = q / RIGID_QUADS, qc = q - tr * RIGID_QUADS;
+        float* d = tileS + tr * RIGID_RSTRIDE + qc;
+        d[0] = pre[i].x;
+        d[RIGID_PLANE] = pre[i].y;
+        d[2 * RIGID_PLANE] = pre[i].z;
+        d[3 * RIGID_PLANE] = pre[i].w;
+      }
+    }
+  };
+
+  fetch(f_lo);
+  park();
+  __syncthreads();
+  for (int f = f_lo; f < f_hi; ++f) {
+    if (f + 1 < f_hi) fetch(f + 1);
+    const int Sx = a.S[2 * f + 1];
+    const int m = (xt + Sx - 1) & 3;
+    // row weights of this wave's strip: Wy[f][y][5] -> 40 consecutive floats, one per lane
+    float wyv = 0.f;
+    {
+      const int64_t idx = (int64_t)y0 * 5 + lane;
+      if (lane < 5 * RIGID_ROWS && idx < (int64_t)h * 5) wyv = a.Wy[(int64_t)f * 5 * h + idx];
+    }
+    float wx[5][4];
+    const float* Wx = a.Wx + (int64_t)f * 5 * w + x0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      if (full) {
+        const float4 t = *reinterpret_cast<const float4*>(Wx + (int64_t)j * w);
+        wx[j][0] = t.x; wx[j][1] = t.y; wx[j][2] = t.z; wx[j][3] = t.w;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wx[j][k] = (x0 + k < w) ? Wx[(int64_t)j * w + k] : 0.f;
+      }
+    }
+    // per-tap LDS offsets (wave-uniform): plane (m+j)&3, index lane + ((m+j)>>2)
+    int toff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) toff[j] = ((m + j) & 3) * RIGID_PLANE + ((m + j) >> 2);
+    const float* wrow = tileS + (wave * RIGID_ROWS) * RIGID_RSTRIDE + lane;
+    float H[5][4];
+#pragma unroll
+    for (int rr = 0; rr < RIGID_ROWS + 4; ++rr) {
+      // keep at most two rows of LDS reads in flight: without this the scheduler hoists
+      // all 96 reads and the kernel needs > 240 VGPRs
+      if ((rr & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+      const float* src = wrow + rr * RIGID_RSTRIDE;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = src[toff[j]];
+      float* Hn = H[rr % 5];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        Hn[k] = (((wx[0][k] * v[k] + wx[1][k] * v[k + 1]) + wx[2][k] * v[k + 2]) +
+                 wx[3][k] * v[k + 3]) + wx[4][k] * v[k + 4];
+      if (rr >= 4) {
+        const int ro = rr - 4;
+        const int yo = y0 + ro;
+        float wy[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) wy[i] = __builtin_amdgcn_readlane(wyv, ro * 5 + i);
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          o[k] = (((wy[0] * H[(ro + 0) % 5][k] + wy[1] * H[(ro + 1) % 5][k]) +
+                   wy[2] * H[(ro + 2) % 5][k]) + wy[3] * H[(ro + 3) % 5][k]) +
+                 wy[4] * H[(ro + 4) % 5][k];
+        if (yo < h && x0 < w) {
+          if (WRITE_FRAMES) {
+            float* dst = a.out_frames + (int64_t)f * hw + (int64_t)yo * w + x0;
+            if (full) {
+              *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+              for (int k = 0; k < 4 && x0 + k < w; ++k) dst[k] = o[k];
+            }
+          }
+          if (WRITE_SUM) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[ro][k] += o[k];
+          }
+        }
+      }
+    }
+    __syncthreads();  // everyone is done reading the tile of frame f
+    if (f + 1 < f_hi) {
+      park();
+      __syncthreads();
+    }
+  }
+  if (WRITE_SUM && x0 < w) {
+#pragma unroll
+    for (int ro = 0; ro < RIGID_ROWS; ++ro) {
+      const int yo = y0 + ro;
+      if (yo < h) {
+        float* dst = a.out_sum + (int64_t)yo * w + x0;
+        for (int k = 0; k < 4 && x0 + k < w; ++k) dst[k] += acc[ro][k];
+      }
+    }
+  }
+}
+#pragma clang fp contract(off)
 
 // get_pixel_shifts (correct_motion.py:132-185) for one lattice: out (h, w, 2) px.
 __global__ void warp_pixel_shifts(const float* __restrict__ etab, const int* __restrict__ ytap,
@@ -320,11 +678,18 @@ int mc_warp_frames(const float* frames, int nframes, int h, int w, const float* 
   a.ytap = ytap; a.ycoef = ycoef; a.pixel_spacing = pixel_spacing;
   a.out_frames = out_frames; a.out_sum = out_sum;
   a.tiles_x = (w + WARP_TX * WARP_PX - 1) / (WARP_TX * WARP_PX);
-  a.tiles_y = (h + WARP_TY * 2 - 1) / (WARP_TY * 2);
+  a.tiles_y = (h + WARP_TY * WARP_ROWS - 1) / (WARP_TY * WARP_ROWS);
   dim3 grid(a.tiles_x * a.tiles_y), block(WARP_TX, WARP_TY);
-  if (out_frames && out_sum) hipLaunchKernelGGL((warp_main<true, true>), grid, block, 0, s, a);
-  else if (out_frames) hipLaunchKernelGGL((warp_main<true, false>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((warp_main<false, true>), grid, block, 0, s, a);
+  const bool unit = (pixel_spacing == 1.0f);
+#define MC_WARP_LAUNCH(F, S)                                                     \
+  do {                                                                           \
+    if (unit) hipLaunchKernelGGL((warp_main<F, S, true>), grid, block, 0, s, a); \
+    else hipLaunchKernelGGL((warp_main<F, S, false>), grid, block, 0, s, a);     \
+  } while (0)
+  if (out_frames && out_sum) MC_WARP_LAUNCH(true, true);
+  else if (out_frames) MC_WARP_LAUNCH(true, false);
+  else MC_WARP_LAUNCH(false, true);
+#undef MC_WARP_LAUNCH
   return mc_check_launch();
 }
 
@@ -345,6 +710,39 @@ int mc_pixel_shifts(const float* lattice, int GH, int GW, int h, int w, float pi
                      xtap, xcoef, etab);
   hipLaunchKernelGGL(warp_pixel_shifts, dim3((w + 255) / 256, h), dim3(256), 0, s, etab, ytap, ycoef,
                      h, w, GH, pixel_spacing, out);
+  return mc_check_launch();
+}
+
+int mc_warp_rigid_scratch_bytes(int nframes, int h, int w, int64_t* bytes) {
+  if (!bytes || nframes < 1 || h < 2 || w < 2) return MC_ERR_ARG;
+  *bytes = ((int64_t)nframes * 5 * (h + w) + 2 * (int64_t)nframes + 8) * 4;
+  return MC_OK;
+}
+
+int mc_warp_rigid(const float* frames, int nframes, int h, int w, const float* shifts_px,
+                  float* scratch, float* out_frames, float* out_sum, void* stream) {
+  if (!frames || !shifts_px || !scratch || (!out_frames && !out_sum)) return MC_ERR_ARG;
+  if (nframes < 1 || h < 2 || w < 2 || (((uintptr_t)scratch) & 15)) return MC_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  float* Wy = scratch;
+  float* Wx = Wy + (int64_t)nframes * 5 * h;
+  int* S = reinterpret_cast<int*>(Wx + (int64_t)nframes * 5 * w);
+  hipError_t e = hipMemsetAsync(S, 0x7f, sizeof(int) * 2 * nframes, s);
+  if (e != hipSuccess) return (int)e;
+  const int n = h > w ? h : w;
+  dim3 tg((n + 255) / 256, nframes, 2);
+  hipLaunchKernelGGL(rigid_base, tg, dim3(256), 0, s, shifts_px, nframes, h, w, S);
+  hipLaunchKernelGGL(rigid_weights, tg, dim3(256), 0, s, shifts_px, nframes, h, w, S, Wy, Wx);
+  RigidArgs a;
+  a.frames = frames; a.nframes = nframes; a.h = h; a.w = w; a.S = S; a.Wy = Wy; a.Wx = Wx;
+  a.out_frames = out_frames; a.out_sum = out_sum;
+  a.tiles_x = (w + RIGID_LANES * 4 - 1) / (RIGID_LANES * 4);
+  a.tiles_y = (h + RIGID_WAVES * RIGID_ROWS - 1) / (RIGID_WAVES * RIGID_ROWS);
+  a.frames_in_grid = out_sum ? 0 : 1;  // without the fused sum every frame is its own block
+  dim3 grid(a.tiles_x * a.tiles_y, a.frames_in_grid ? nframes : 1), block(RIGID_LANES, RIGID_WAVES);
+  if (out_frames && out_sum) hipLaunchKernelGGL((warp_rigid<true, true>), grid, block, 0, s, a);
+  else if (out_frames) hipLaunchKernelGGL((warp_rigid<true, false>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((warp_rigid<false, true>), grid, block, 0, s, a);
   return mc_check_launch();
 }
 

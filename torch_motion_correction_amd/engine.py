@@ -240,17 +240,26 @@ def frame_lattices(field, t, grid_type):
 # ------------------------------------------------------------------ a15/a17/a18: warp
 
 
-def warp(img, lattices, pixel_spacing, want_frames=True, want_sum=False):
-    """Resample every frame through its lattice; returns (frames or None, sum or None)."""
+def warp(img, lattices, pixel_spacing, want_frames=True, want_sum=False, rigid=False):
+    """Resample every frame through its lattice; returns (frames or None, sum or None).
+    rigid=True: the lattices come from a (2,nt,1,1) field, i.e. one shift per frame ->
+    the separable rigid kernel."""
     lib = _lib.load()
     t, h, w = img.shape
     dev = img.device
     _, _, GH, GW = lattices.shape
-    nbytes = C.c_int64(0)
-    check(lib.mc_warp_scratch_bytes(t, h, w, GH, GW, C.byref(nbytes)), "mc_warp_scratch_bytes")
-    scratch = torch.empty((nbytes.value + 3) // 4, dtype=torch.float32, device=dev)
     frames = torch.empty_like(img) if want_frames else None
     total = torch.zeros((h, w), dtype=torch.float32, device=dev) if want_sum else None
+    nbytes = C.c_int64(0)
+    if rigid:
+        shifts_px = (lattices[:, :, 0, 0] / pixel_spacing).contiguous()  # shifts_angstroms / ps
+        check(lib.mc_warp_rigid_scratch_bytes(t, h, w, C.byref(nbytes)), "mc_warp_rigid_scratch_bytes")
+        scratch = torch.empty((nbytes.value + 3) // 4, dtype=torch.float32, device=dev)
+        check(lib.mc_warp_rigid(ptr(img), t, h, w, ptr(shifts_px), ptr(scratch), ptr(frames),
+                                ptr(total), stream_ptr(dev)), "mc_warp_rigid")
+        return frames, total
+    check(lib.mc_warp_scratch_bytes(t, h, w, GH, GW, C.byref(nbytes)), "mc_warp_scratch_bytes")
+    scratch = torch.empty((nbytes.value + 3) // 4, dtype=torch.float32, device=dev)
     check(lib.mc_warp_frames(ptr(img), t, h, w, ptr(lattices), GH, GW, float(pixel_spacing),
                              ptr(scratch), ptr(frames), ptr(total), stream_ptr(dev)),
           "mc_warp_frames")
