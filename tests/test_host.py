@@ -1,0 +1,240 @@
+"""CPU tests of the product's host logic (no GPU, no compute calls into libmcorr):
+lattice + memo replay pinned by the reference's goldens, pruning geometry proven
+conservative against the oracle's filters/mask, spline tap tables against the
+oracle's spline, C-ABI symbol export, and world_size-2 gloo sharding."""
+
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from oracle import thirdparty_semantics as tp
+from torch_motion_correction_amd import _lib, lattice, multi_gpu, plan, spline
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ lattice / memo replay
+
+
+def test_patch_centres_match_reference(golden):
+    g = golden("patch_grid_reference.npz")
+    for key in g.files:
+        if key.startswith("centers_"):
+            _, dim, p = key.split("_")
+            assert np.array_equal(lattice.patch_centers_1d(int(dim), int(p), int(p) // 2), g[key]), key
+
+
+def test_baseline_config_lattices():
+    """SURVEY.md section 8 header: p=1024 -> C2 6x6, C3 6x10, C5 14x21."""
+    assert [len(a) for a in lattice.patch_grid_centers(40, 4096, 4096, 1024)] == [6, 6]
+    assert [len(a) for a in lattice.patch_grid_centers(40, 4092, 5760, 1024)] == [6, 10]
+    assert [len(a) for a in lattice.patch_grid_centers(60, 8184, 11520, 1024)] == [14, 21]
+    cy, _ = lattice.patch_grid_centers(40, 4096, 4096, 1024)
+    assert cy.tolist() == [512, 1126, 1740, 2355, 2969, 3583]
+
+
+@pytest.mark.parametrize("t", [5, 8, 40, 51, 60])
+@pytest.mark.parametrize("strategy", ["middle_frame", "mean_except_current"])
+def test_mask_schedule_matches_reference(golden, t, strategy):
+    g = golden("patch_grid_reference.npz")
+    ref_expo, cur_expo, processed = lattice.mask_schedule(t, strategy, t // 2)
+    assert np.array_equal(ref_expo, g[f"exp_{strategy}_{t}"])
+    assert np.array_equal(cur_expo, g[f"cur_{strategy}_{t}"])
+    expect = [f for f in range(t) if not (strategy == "middle_frame" and f == t // 2)]
+    assert processed == expect
+
+
+def test_mask_schedule_unknown_strategy():
+    with pytest.raises(ValueError, match="Unknown reference_strategy"):
+        lattice.mask_schedule(5, "nope", 2)
+
+
+def test_centers_tensor_layout():
+    cy, cx = lattice.patch_grid_centers(3, 64, 96, 32)
+    c = lattice.centers_tensor(3, cy, cx)
+    assert c.shape == (3, len(cy), len(cx), 3) and c.dtype == torch.int64
+    assert c[2, 1, 0].tolist() == [2, int(cy[1]), int(cx[0])]
+
+
+# ------------------------------------------------------------------ pruning geometry
+
+
+@pytest.mark.parametrize("n,ps,fr", [(64, 1.0, (300, 10)), (256, 1.0, (300, 10)), (512, 0.83, (300, 10)),
+                                     (128, 1.5, (200, 20)), (64, 6.0, (300, 10))])
+def test_geometry_is_a_superset_of_the_filter_support(n, ps, fr):
+    low, high = plan.band_limits(fr, ps)
+    g = plan.xc_geometry(n, n, high, n / 4, n / 8)
+    filt = oracle.prepare_bandpass_filter(fr, (n, n), ps) * tp.b_envelope(500, (n, n), ps)
+    rows = list(range(g.kyp)) + list(range(n - g.kyn, n))
+    outside = filt.clone()
+    outside[rows, : g.nkx] = 0
+    assert float(outside.abs().max()) == 0.0, "a non-zero filter bin would be pruned away"
+    assert g.kyp + g.kyn <= n and 1 <= g.nkx <= n // 2 + 1
+    mask = tp.circle(n / 4, (n, n), smoothing_radius=n / 8)
+    outside = mask.clone()
+    outside[g.y0 : g.y0 + g.ny, g.x0 : g.x1] = 0
+    assert float(outside.abs().max()) == 0.0, "a non-zero mask pixel would never be read"
+    assert g.ny % g.RG == 0 and n % g.RG == 0 and g.x0 % 2 == 0 and g.x1 % 2 == 0
+
+
+def test_headline_geometry_prunes():
+    """40x4096^2 at 1 A/px, (300,10) A: ~10 % of the columns, ~20 % of the rows kept."""
+    low, high = plan.band_limits((300, 10), 1.0)
+    g = plan.xc_geometry(4096, 4096, high, 1024, 512)
+    assert (g.nkx, g.kyp, g.kyn) == (410, 410, 409)
+    assert g.ny <= 3104 and g.x1 - g.x0 <= 3104
+
+
+def test_full_geometry_keeps_everything():
+    g = plan.full_geometry(64, 128)
+    assert (g.nkx, g.kyp, g.kyn, g.y0, g.ny, g.x0, g.x1) == (65, 64, 0, 0, 64, 0, 128)
+
+
+def test_unsupported_sizes_fail_loudly():
+    with pytest.raises(NotImplementedError, match="power-of-two"):
+        plan.xc_geometry(4092, 5760, 0.1, 1000, 500)
+
+
+def test_band_limits_follow_reference_ops():
+    low, high = plan.band_limits((300, 10), 1.0)
+    assert low == pytest.approx(1 / 300, rel=1e-6) and high == pytest.approx(0.1, rel=1e-6)
+    assert np.float32(high) == np.float32(torch.as_tensor(1 / torch.tensor(10.0)) * 1.0)
+
+
+def test_twiddles():
+    tw = plan.twiddles(8, "cpu").numpy()
+    k = np.arange(8)
+    assert np.allclose(tw[:, 0], np.cos(2 * np.pi * k / 8), atol=1e-7)
+    assert np.allclose(tw[:, 1], -np.sin(2 * np.pi * k / 8), atol=1e-7)
+
+
+# ------------------------------------------------------------------ spline taps
+
+
+@pytest.mark.parametrize("kind", ["catmull_rom", "bspline"])
+@pytest.mark.parametrize("shape", [(4, 3, 5), (5, 1, 1), (2, 2, 2), (1, 1, 1), (6, 1, 4)])
+def test_axis_taps_reproduce_oracle_spline(kind, shape):
+    g = torch.Generator().manual_seed(3)
+    data = torch.randn(2, *shape, generator=g)
+    ut, uy, ux = torch.linspace(0, 1, 7), torch.rand(5, generator=g), torch.linspace(0, 1, 6)
+    taps = [spline.axis_taps(n, u, kind) for n, u in zip(shape, (ut, uy, ux))]
+    out = torch.zeros(2, 7, 5, 6)
+    for it in range(7):
+        for iy in range(5):
+            for ix in range(6):
+                acc = torch.zeros(2)
+                for kt in range(4):
+                    for ky in range(4):
+                        for kx in range(4):
+                            w = taps[0][1][it, kt] * taps[1][1][iy, ky] * taps[2][1][ix, kx]
+                            acc += w * data[:, taps[0][0][it, kt], taps[1][0][iy, ky], taps[2][0][ix, kx]]
+                out[:, it, iy, ix] = acc
+    tyx = torch.stack(torch.meshgrid(ut, uy, ux, indexing="ij"), -1)
+    ref = tp.cubic_spline_grid_3d(data, tyx, kind).permute(3, 0, 1, 2)
+    assert torch.allclose(out, ref, atol=2e-5)
+
+
+def test_axis_taps_bad_kind():
+    with pytest.raises(ValueError, match="grid_type"):
+        spline.axis_taps(4, torch.linspace(0, 1, 3), "linear")
+
+
+# ------------------------------------------------------------------ C ABI
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "mcorr.h")).read()
+    declared = set(re.findall(r"^int\s+(mc_\w+)\s*\(", header, flags=re.M))
+    assert len(declared) >= 20
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.mc_abi_version() == 1
+
+
+def test_abi_rejects_bad_arguments_without_touching_the_gpu():
+    lib = _lib.load()
+    g = plan.xc_geometry(64, 64, 0.1, 16, 8)
+    assert lib.mc_xc_rows_lds_bytes(g) > 0
+    bad = _lib.XcGeom(W=100, H=64, nkx=5, kyp=5, kyn=4, y0=0, ny=64, x0=0, x1=100, RG=16)
+    assert lib.mc_xc_rows_lds_bytes(bad) == -2  # MC_ERR_UNSUPPORTED: not a power of two
+    n = ctypes.c_int64(0)
+    assert lib.mc_warp_scratch_bytes(4, 64, 64, 10, 10, ctypes.byref(n)) == 0 and n.value > 0
+    assert lib.mc_warp_rigid_scratch_bytes(4, 64, 64, ctypes.byref(n)) == 0 and n.value > 0
+    assert lib.mc_circle_mask(None, None, 64, 64, 16.0, 8.0, None) == -1  # MC_ERR_ARG
+    assert lib.mc_warp_frames(None, 1, 64, 64, None, 10, 10, 1.0, None, None, None, None) == -1
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "torch_motion_correction_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), fn
+
+
+def test_no_gpu_means_loud_failure():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import torch_motion_correction_amd as mc
+
+    with pytest.raises(mc.McorrError, match="no CPU fallback"):
+        mc.estimate_global_motion(torch.zeros(3, 64, 64), 1.0)
+
+
+# ------------------------------------------------------------------ sharding (gloo, 2 ranks)
+
+
+def test_round_robin_assignment():
+    a = multi_gpu.assignment(64, 8)
+    assert all(len(x) == 8 for x in a)
+    assert sorted(i for x in a for i in x) == list(range(64))
+    assert multi_gpu.movies_for_rank(5, 1, 2) == [1, 3]
+    assert multi_gpu.movies_for_rank(1, 1, 2) == []  # ragged: more ranks than movies
+    with pytest.raises(ValueError):
+        multi_gpu.movies_for_rank(4, 2, 2)
+
+
+def _rank_main(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_movies = 5
+        mine = multi_gpu.movies_for_rank(n_movies, rank, world)
+        # a CPU stand-in for the per-movie work: each movie's known integer drift is
+        # "estimated" from its id alone, so the gathered table can be checked exactly
+        local = multi_gpu.process_shard(mine, load=lambda i: torch.full((2,), float(i)),
+                                        work=lambda x: (x * 2).tolist())
+        dist.barrier()
+        merged = multi_gpu.gather_results(local, world)
+        elapsed = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)  # the bench's max-over-ranks
+        q.put((rank, mine, merged, float(elapsed)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharding():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    results.sort()
+    assert results[0][1] == [0, 2, 4] and results[1][1] == [1, 3]
+    for _, _, merged, elapsed in results:
+        assert merged == {i: [2.0 * i, 2.0 * i] for i in range(5)}
+        assert elapsed == pytest.approx(0.2)

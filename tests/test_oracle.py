@@ -1,0 +1,236 @@
+"""CPU tests of the oracle: pinned against the reference-produced goldens, against the
+assertions of the reference's own test-suite, and against its own committed outputs."""
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import patch_grid as opg
+from oracle import thirdparty_semantics as tp
+from conftest import blob_stack, drift_stack, ramp_field
+
+
+# ---------------------------------------------------------------- pinned by the reference
+
+
+def test_patch_centres_match_reference(golden):
+    g = golden("patch_grid_reference.npz")
+    n = 0
+    for key in g.files:
+        if key.startswith("centers_"):
+            _, dim, p = key.split("_")
+            got = opg.centers_1d(int(dim), int(p), int(p) // 2, True).numpy()
+            assert np.array_equal(got, g[key]), key
+            n += 1
+    assert n >= 10
+
+
+def test_lazy_gather_matches_reference(golden):
+    g = golden("patch_grid_reference.npz")
+    img = torch.from_numpy(g["gather_img"])
+    lazy, centers = opg.patch_grid_lazy(img, (1, 16, 16), (1, 8, 8), True)
+    assert np.array_equal(centers.numpy(), g["gather_centers"])
+    assert np.array_equal(lazy[1].numpy(), g["gather_frame1"])
+    assert lazy[1] is lazy[1]  # memoised: the same tensor object is handed out again
+
+
+@pytest.mark.parametrize("t", [5, 8, 40, 51, 60])
+@pytest.mark.parametrize("strategy", ["middle_frame", "mean_except_current"])
+def test_memo_aliasing_schedule_matches_reference(golden, t, strategy):
+    """Replay xc.py:297-346's access pattern on the oracle's LazyPatches with a scalar
+    mask of 2.0: the exponents must equal what the reference's own class produced."""
+    g = golden("patch_grid_reference.npz")
+    imgs = torch.ones(t, 8, 8)
+    lz, _ = opg.patch_grid_lazy(imgs, (1, 4, 4), (1, 2, 2), True)
+    ref = t // 2
+    table = np.full((t, t), -1, dtype=np.int64)
+    cur = np.full((t,), -1, dtype=np.int64)
+    for f in range(t):
+        r = None
+        if strategy == "middle_frame":
+            if f == ref:
+                continue
+            r = lz[ref][0, :, :, 0]
+            table[f, ref] = int(torch.log2(r.flatten()[0]))
+        else:
+            for o in range(t):
+                if o != f:
+                    table[f, o] = int(torch.log2(lz[o].flatten()[0]))
+        c = lz[f][0, :, :, 0]
+        cur[f] = int(torch.log2(c.flatten()[0]))
+        if r is not None:
+            r *= 2.0
+        c *= 2.0
+    assert np.array_equal(table, g[f"exp_{strategy}_{t}"])
+    assert np.array_equal(cur, g[f"cur_{strategy}_{t}"])
+
+
+# ------------------------------------------- the reference's own test assertions
+
+
+def test_ref_suite_global_shapes():
+    mov = blob_stack(True)
+    for kw in ({}, {"reference_frame": 0}, {"b_factor": 1000}, {"frequency_range": (200, 20)}):
+        f = oracle.estimate_global_motion(mov, 1.0, **kw)
+        assert isinstance(f, torch.Tensor) and f.shape == (2, 5, 1, 1)
+
+
+@pytest.mark.parametrize("kw", [
+    {}, {"reference_strategy": "middle_frame"},
+    {"sub_pixel_refinement": False, "outlier_rejection": False},
+    {"smoothing_window_size": 3}, {"outlier_threshold": 2.0}, {"temporal_smoothing": False},
+    {"outlier_rejection": False},
+])
+def test_ref_suite_patches_shapes(kw):
+    mov = blob_stack(True)
+    f, pos = oracle.estimate_motion_cross_correlation_patches(mov, 1.0, patch_sidelength=32, **kw)
+    assert f.ndim == 4 and f.shape[0] == 2 and f.shape[1] == 5
+    assert pos.ndim == 4 and pos.shape[0] == 5 and pos.dtype == torch.int64
+
+
+def test_q12_integer_peaks_with_outlier_rejection_raise():
+    """Reference accident: without sub-pixel refinement the shifts are int64 and
+    torch.std (xc.py:577) rejects them -- the combination raises in the reference."""
+    with pytest.raises(RuntimeError, match="floating point"):
+        oracle.estimate_motion_cross_correlation_patches(blob_stack(True), 1.0, patch_sidelength=32,
+                                                         sub_pixel_refinement=False)
+
+
+def test_ref_suite_patches_with_initial_field():
+    mov = blob_stack(True)
+    f, _ = oracle.estimate_motion_cross_correlation_patches(
+        mov, 1.0, patch_sidelength=32, deformation_field=torch.zeros(2, 5, 1, 1))
+    assert f.shape[0] == 2 and torch.isfinite(f).all()
+
+
+def test_ref_suite_unknown_strategy():
+    with pytest.raises(ValueError, match="Unknown reference_strategy"):
+        oracle.estimate_motion_cross_correlation_patches(blob_stack(True), 1.0, patch_sidelength=32,
+                                                         reference_strategy="nope")
+
+
+@pytest.mark.parametrize("grid_type", ["catmull_rom", "bspline"])
+def test_ref_suite_correct_motion(grid_type):
+    stat = blob_stack(False)
+    out = oracle.correct_motion(stat, ramp_field(), 1.0, grid_type=grid_type)
+    assert out.shape == stat.shape and not out.requires_grad
+    zero = oracle.correct_motion(stat, torch.zeros(2, 5, 2, 2), 1.0, grid_type=grid_type)
+    assert torch.allclose(zero, stat, atol=0.1)  # tests/test_correct_motion.py:132-145
+    assert torch.allclose(zero, stat, atol=1e-5)  # and much tighter in fact
+
+
+def test_ref_suite_correct_motion_fast():
+    stat = blob_stack(False)
+    out = oracle.correct_motion_fast(stat, ramp_field(g=1))
+    assert out.shape == stat.shape
+    zero = oracle.correct_motion_fast(stat, torch.zeros(2, 5, 1, 1))
+    assert torch.allclose(zero, stat, atol=1e-5)  # tests/test_correct_motion.py:188-199
+    with pytest.raises(ValueError, match="Expected single patch deformation field"):
+        oracle.correct_motion_fast(stat, ramp_field())
+
+
+def test_ref_suite_global_then_correct_is_finite():
+    mov = blob_stack(True)
+    fld = oracle.estimate_global_motion(mov, 1.0)
+    assert torch.isfinite(oracle.correct_motion(mov, fld, 1.0)).all()  # size-1 spline axes
+    assert torch.isfinite(oracle.correct_motion_fast(mov, fld.clone())).all()
+
+
+def test_q1_fast_negates_callers_field():
+    f = ramp_field(g=1)
+    before = f.clone()
+    oracle.correct_motion_fast(blob_stack(False), f)
+    assert torch.equal(f, -before)
+
+
+# --------------------------------------------------------------- own committed outputs
+
+
+def test_oracle_blob_goldens(golden):
+    g = golden("oracle_blob.npz")
+    mov, stat = blob_stack(True), blob_stack(False)
+    assert np.array_equal(oracle.estimate_global_motion(mov, 1.0).numpy(), g["blob_global"])
+    for s in ("mean_except_current", "middle_frame"):
+        f, pos = oracle.estimate_motion_cross_correlation_patches(mov, 1.0, patch_sidelength=32,
+                                                                  reference_strategy=s)
+        assert np.allclose(f.numpy(), g[f"blob_patches_{s}"], atol=2e-5)
+        assert np.array_equal(pos.numpy(), g["blob_patch_pos"])
+    assert np.allclose(oracle.correct_motion(stat, ramp_field(), 1.0).numpy(), g["blob_correct_cr"],
+                       atol=1e-6)
+    assert np.allclose(oracle.correct_motion(stat, ramp_field(), 1.0, grid_type="bspline").numpy(),
+                       g["blob_correct_bs"], atol=1e-6)
+    assert np.allclose(oracle.correct_motion_fast(stat, ramp_field(g=1)).numpy(), g["blob_fast"],
+                       atol=1e-6)
+
+
+def test_oracle_recovers_known_integer_drift(golden):
+    """Known-answer test: the synthetic stack's drift is known exactly."""
+    st, dy, dx = drift_stack(8, 256, 256)
+    f = oracle.estimate_global_motion(st, 1.0)
+    assert torch.equal(f[0, :, 0, 0], (dy - dy[4]).float())
+    assert torch.equal(f[1, :, 0, 0], (dx - dx[4]).float())
+    g = golden("oracle_drift_8x256.npz")
+    assert np.array_equal(f.numpy(), g["global_field"])
+    s = oracle.correct_motion(st, f, 1.0).sum(0)
+    assert np.allclose(s.numpy(), g["corrected_sum"], atol=1e-4)
+
+
+# ------------------------------------------------------------------ semantics spot checks
+
+
+def test_spline_properties():
+    g = torch.Generator().manual_seed(0)
+    data = torch.randn(2, 4, 3, 5, generator=g)
+    knots = torch.stack(torch.meshgrid(torch.linspace(0, 1, 4), torch.linspace(0, 1, 3),
+                                       torch.linspace(0, 1, 5), indexing="ij"), -1)
+    cr = tp.cubic_spline_grid_3d(data, knots, "catmull_rom")
+    assert torch.allclose(cr.permute(3, 0, 1, 2), data, atol=1e-5)  # Catmull-Rom interpolates
+    const = torch.full((2, 4, 3, 5), 3.25)
+    pts = torch.rand(50, 3, generator=g)
+    for kind in ("catmull_rom", "bspline"):
+        assert torch.allclose(tp.cubic_spline_grid_3d(const, pts, kind), torch.full((50, 2), 3.25),
+                              atol=1e-5)
+    one = torch.randn(2, 5, 1, 1, generator=g)  # single-sample axes are constant
+    v = tp.cubic_spline_grid_3d(one, torch.tensor([[0.25, 0.3, 0.9], [0.25, 0.7, 0.1]]), "catmull_rom")
+    assert torch.allclose(v[0], v[1], atol=1e-6) and torch.allclose(v[0], one[:, 1, 0, 0], atol=1e-5)
+
+
+def test_mask_and_filters():
+    m = tp.circle(16, (64, 64), smoothing_radius=8)
+    assert m[32, 32] == 1 and m[32, 47] == 1 and m[32, 48] < 1 and m[0, 0] == 0
+    assert float(m[32, 56]) == pytest.approx(0.0, abs=1e-6) and m.min() >= -1e-7 and m.max() == 1
+    band = oracle.prepare_bandpass_filter((300, 10), (64, 64), 1.0)
+    assert band[0, 0] == 0 and set(band.unique().tolist()) <= {0.0, 1.0}
+    f = tp.fftfreq_grid((64, 64), rfft=True, norm=True)
+    assert torch.equal(band, ((f > 1 / 300) & (f <= 0.1)).float())
+    env = tp.b_envelope(500, (64, 64), 1.0)
+    assert torch.allclose(env, torch.exp(-500 * f**2 / 4))
+
+
+def test_sub_pixel_rules():
+    """Q4: no refinement when the peak touches a border; Q5: axis skipped when symmetric."""
+    from oracle.motion import _sub_pixel
+
+    cc = torch.zeros(1, 8, 8)
+    cc[0, 0, 3] = 1.0
+    cc[0, 1, 3] = 0.5
+    py, px = _sub_pixel(cc, torch.tensor([3]), 8, 8)
+    assert py.item() == 0 and px.item() == 3  # border: untouched
+    cc = torch.zeros(1, 8, 8)
+    cc[0, 3, 3], cc[0, 2, 3], cc[0, 4, 3] = 1.0, 0.2, 0.6
+    py, px = _sub_pixel(cc, torch.tensor([3 * 8 + 3]), 8, 8)
+    assert px.item() == 3  # symmetric in x: skipped
+    assert py.item() == pytest.approx(3 + 0.5 * (0.2 - 0.6) / (0.2 - 2.0 + 0.6))
+
+
+def test_outlier_rejection_rules():
+    from oracle.motion import _reject_outliers
+
+    sy = torch.tensor([[0.0, 0.1, 0.0], [0.1, 9.0, 0.0], [0.1, 0.0, 0.1]])
+    sx = torch.zeros(3, 3)
+    ry, rx = _reject_outliers(sy, sx, 2.0)
+    assert ry[1, 1].item() == pytest.approx(sy.flatten()[[0, 1, 2, 3, 5, 6, 7, 8]].mean().item())
+    same = torch.full((2, 2), 1.5)
+    ry, rx = _reject_outliers(same, same, 3.0)  # zero spread: nothing rejected
+    assert torch.equal(ry, same)

@@ -10,8 +10,9 @@ inputs are staged to the current GPU, computed there and copied back.
 ``BUG_COMPATIBLE`` (default True) keeps the reference's behavioural accidents that
 change numbers or mutate arguments: the in-place negation of
 the caller's field in ``correct_motion_fast`` (Q1) and the mask-exponent schedule
-caused by the lazy-patch memo aliasing (Q2/Q3).  Q4-Q9 are plain semantics and are
-always reproduced.
+caused by the lazy-patch memo aliasing (Q2/Q3), and the RuntimeError the reference raises
+for sub_pixel_refinement=False with outlier_rejection=True (Q12: torch.std on int64
+peaks).  Q4-Q9 are plain semantics and are always reproduced.
 """
 
 from __future__ import annotations
@@ -136,6 +137,9 @@ def estimate_motion_cross_correlation_patches(
     ref = t // 2 if reference_frame is None else reference_frame
     if reference_strategy not in ("middle_frame", "mean_except_current"):
         raise ValueError(f"Unknown reference_strategy: {reference_strategy}")
+    if BUG_COMPATIBLE and outlier_rejection and not sub_pixel_refinement:
+        # Q12: integer peak coordinates reach torch.std at estimate_motion_xc.py:577
+        raise RuntimeError("std and var only support floating point and complex dtypes")
     stats = engine.central_box_stats(img)  # statistics of the *uncorrected* stack (Q9)
     field0 = None
     if deformation_field is not None:

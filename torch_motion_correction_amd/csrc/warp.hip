@@ -541,7 +541,8 @@ __global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES, RIGID_MINW) void warp_rig
         const int yo = y0 + ro;
         float wy[5];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) wy[i] = __builtin_amdgcn_readlane(wyv, ro * 5 + i);
+        for (int i = 0; i < 5; ++i)
+          wy[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wyv), ro * 5 + i));
         float o[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
