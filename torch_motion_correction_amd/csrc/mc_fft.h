@@ -70,6 +70,148 @@ __device__ __forceinline__ void bfly(cfloat* a) {
   else bfly2<DIR>(a);
 }
 
+// ---------------------------------------------------------------------------------
+// Pass plan of a length-N transform: radix 8 while possible, then one 4 or 2.
+template <int N>
+struct FftPlan {
+  static constexpr int npass() {
+    int n = N, p = 0;
+    while (n > 1) {
+      n /= (n >= 8 ? 8 : n);
+      ++p;
+    }
+    return p;
+  }
+  static constexpr int radix(int pass) {
+    int n = N, r = 1;
+    for (int p = 0; p <= pass; ++p) {
+      r = n >= 8 ? 8 : n;
+      n /= r;
+    }
+    return r;
+  }
+  static constexpr int ns(int pass) {  // product of the radices before `pass`
+    int n = 1;
+    for (int p = 0; p < pass; ++p) n *= radix(p);
+    return n;
+  }
+  static constexpr int iters(int pass) { return (N / radix(pass) + MC_WG - 1) / MC_WG; }
+  static constexpr int max_iters() {
+    int m = 1;
+    for (int p = 0; p < npass(); ++p) m = iters(p) > m ? iters(p) : m;
+    return m;
+  }
+};
+
+// Per-thread twiddle bases: the same for every line a thread transforms, so kernels
+// that loop over many lines load them once.  w[pass][it] = exp(-+2 pi i k / (NS*R)).
+template <int N>
+struct FftTwiddles {
+  static constexpr int P = FftPlan<N>::npass();
+  cfloat w[P > 1 ? P - 1 : 1][FftPlan<N>::max_iters()];
+  template <int DIR>
+  __device__ __forceinline__ void init(int tid, const cfloat* __restrict__ tw, int tw_stride) {
+#pragma unroll
+    for (int p = 1; p < P; ++p) {
+      const int R = FftPlan<N>::radix(p), NS = FftPlan<N>::ns(p), NB = N / R;
+      const int IT = (NB + MC_WG - 1) / MC_WG;
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int j = tid + it * MC_WG;
+        const int k = j & (NS - 1);
+        cfloat v = tw[(j < NB ? k : 0) * (N / (NS * R)) * tw_stride];
+        if (DIR > 0) v.y = -v.y;
+        w[p - 1][it] = v;
+      }
+    }
+  }
+};
+
+// One Stockham pass (index PASS of the plan).  LOAD/STORE functors as in wg_fft.
+template <int N, int PASS, int DIR, typename Load, typename Store>
+__device__ __forceinline__ void fft_pass2(int tid, const FftTwiddles<N>& T, Load load, Store store) {
+  constexpr int R = FftPlan<N>::radix(PASS);
+  constexpr int NS = FftPlan<N>::ns(PASS);
+  constexpr int NB = N / R;
+  constexpr int IT = (NB + MC_WG - 1) / MC_WG;
+  cfloat v[IT][R];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int j = tid + it * MC_WG;
+    if (NB >= MC_WG || j < NB) {
+#pragma unroll
+      for (int m = 0; m < R; ++m) v[it][m] = load(j + m * NB, it, m);
+      if constexpr (NS > 1) {
+        const cfloat w1 = T.w[PASS - 1][it];
+        v[it][1] = cmul(v[it][1], w1);
+        if constexpr (R >= 4) {
+          const cfloat w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+          v[it][2] = cmul(v[it][2], w2);
+          v[it][3] = cmul(v[it][3], w3);
+          if constexpr (R == 8) {
+            const cfloat w4 = cmul(w2, w2), w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3);
+            v[it][4] = cmul(v[it][4], w4);
+            v[it][5] = cmul(v[it][5], w5);
+            v[it][6] = cmul(v[it][6], w6);
+            v[it][7] = cmul(v[it][7], w7);
+          }
+        }
+      }
+      bfly<R, DIR>(v[it]);
+      const int k = j & (NS - 1);
+      const int base = (j - k) * R + k;
+#pragma unroll
+      for (int m = 0; m < R; ++m) store(base + m * NS, v[it][m]);
+    }
+  }
+}
+
+// Ping-pong transform over two LDS lines: pass p reads line[(s+p-1)&1] (p>0) and writes
+// line[(s+p)&1]; one barrier after every LDS-writing pass, none between a pass's reads
+// and writes.  The first pass reads through `load(i, it, m)` (it, m = position of
+// element i in this thread's first-pass registers, for register-prefetched inputs);
+// the last pass writes through `store(i, v)` when LAST_TO_FUNCTOR, else to LDS.
+// Returns the index of the line holding the result (when written to LDS).
+// Buffer discipline for loops: start the next line at (result_line ^ 1) -- see xc_fft.hip.
+template <int N, int DIR, bool LAST_TO_FUNCTOR, int PASS, typename Load, typename Store>
+__device__ __forceinline__ int fft_pp_rec(cfloat* l0, cfloat* l1, int s, int tid,
+                                          const FftTwiddles<N>& T, Load load, Store store) {
+  constexpr int P = FftPlan<N>::npass();
+  cfloat* src = ((s + PASS + 1) & 1) ? l1 : l0;
+  cfloat* dst = ((s + PASS) & 1) ? l1 : l0;
+  auto lds_load = [src](int i, int, int) { return src[lpad(i)]; };
+  auto lds_store = [dst](int i, cfloat v) { dst[lpad(i)] = v; };
+  constexpr bool LAST = (PASS == P - 1);
+  if constexpr (PASS == 0 && LAST) {
+    if constexpr (LAST_TO_FUNCTOR) fft_pass2<N, PASS, DIR>(tid, T, load, store);
+    else { fft_pass2<N, PASS, DIR>(tid, T, load, lds_store); __syncthreads(); }
+    return (s + PASS) & 1;
+  } else if constexpr (PASS == 0) {
+    fft_pass2<N, PASS, DIR>(tid, T, load, lds_store);
+    __syncthreads();
+    return fft_pp_rec<N, DIR, LAST_TO_FUNCTOR, PASS + 1>(l0, l1, s, tid, T, load, store);
+  } else if constexpr (LAST) {
+    if constexpr (LAST_TO_FUNCTOR) {
+      fft_pass2<N, PASS, DIR>(tid, T, lds_load, store);
+      return (s + PASS + 1) & 1;
+    } else {
+      fft_pass2<N, PASS, DIR>(tid, T, lds_load, lds_store);
+      __syncthreads();
+      return (s + PASS) & 1;
+    }
+  } else {
+    fft_pass2<N, PASS, DIR>(tid, T, lds_load, lds_store);
+    __syncthreads();
+    return fft_pp_rec<N, DIR, LAST_TO_FUNCTOR, PASS + 1>(l0, l1, s, tid, T, load, store);
+  }
+}
+
+template <int N, int DIR, bool LAST_TO_FUNCTOR, typename Load, typename Store>
+__device__ __forceinline__ int wg_fft_pp(cfloat* l0, cfloat* l1, int s, int tid,
+                                         const FftTwiddles<N>& T, Load load, Store store) {
+  return fft_pp_rec<N, DIR, LAST_TO_FUNCTOR, 0>(l0, l1, s, tid, T, load, store);
+}
+
 // One Stockham pass of radix R at sub-transform length NS (product of earlier
 // radices).  tw = table of exp(-2*pi*i*k/L), L = N * tw_stride.
 template <int N, int R, int NS, int DIR, bool SYNC_MID, bool SYNC_END, typename Load, typename Store>

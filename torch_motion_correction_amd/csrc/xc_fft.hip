@@ -16,6 +16,8 @@
 //   K4 xc_rows_inv   rows:  T2 rows -> inverse real FFT(W) -> fused arg-max | store
 //   K5 xc_peak_final       reduce K4's per-workgroup candidates, decode wrap-around
 //   K6 xc_peak_nbhd        re-evaluate rows y-1,y,y+1 of one map for the parabola fit
+#include <stdlib.h>
+#include <string.h>
 #include "mc_fft.h"
 #include "mcorr.h"
 
@@ -29,16 +31,21 @@ struct XcGeom {
 };
 
 // ------------------------------------------------------------------ K1: rows forward
-template <int LOGN>
+// Two LDS lines (ping-pong: one barrier per pass), twiddles in registers for the whole
+// row loop, and the next row's samples + mask values already in flight (registers)
+// while the current row is transformed.
+template <int LOGN, int PREFETCH>
 __global__ __launch_bounds__(MC_WG) void xc_rows_fwd(
     const float* __restrict__ src, const int64_t* __restrict__ job_off, int64_t row_stride,
     const int* __restrict__ job_expo, const float* __restrict__ mask,
     const float* __restrict__ mean_rstd, cfloat* __restrict__ T1,
     const cfloat* __restrict__ tw_row, XcGeom g) {
   constexpr int N = 1 << LOGN;  // complex length = W/2
+  constexpr int R0 = FftPlan<N>::radix(0), NB0 = N / R0, IT0 = FftPlan<N>::iters(0);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  cfloat* line = reinterpret_cast<cfloat*>(smem);
-  cfloat* stg = line + lds_len(N);
+  cfloat* l0 = reinterpret_cast<cfloat*>(smem);
+  cfloat* l1 = l0 + lds_len(N);
+  cfloat* stg = l1 + lds_len(N);
   const int tid = threadIdx.x;
   const int job = blockIdx.y;
   const int grp = blockIdx.x;
@@ -47,41 +54,70 @@ __global__ __launch_bounds__(MC_WG) void xc_rows_fwd(
   const float rstd = mean_rstd ? mean_rstd[1] : 1.f;
   const int expo = job_expo ? job_expo[job] : (mask ? 1 : 0);
   const float* base = src + job_off[job];
+  FftTwiddles<N> T;
+  T.template init<-1>(tid, tw_row, 2);
 
-  for (int r = 0; r < RG; ++r) {
+  cfloat pxA[IT0][R0], mkA[IT0][R0], pxB[IT0][R0], mkB[IT0][R0];
+  auto issue = [&](int r, cfloat (&p)[IT0][R0], cfloat (&m)[IT0][R0]) {
     const int y = g.y0 + grp * RG + r;
     const float* row = base + (int64_t)y * row_stride;
-    const float* mrow = mask ? mask + (int64_t)y * g.W : nullptr;
-    auto load = [&](int n) {
-      const int x = 2 * n;
-      cfloat v = cmake(0.f, 0.f);
-      if (x >= g.x0 && x < g.x1) {
-        v.x = (row[x] - mean) * rstd;
-        v.y = (row[x + 1] - mean) * rstd;
-        if (expo > 0) {
-          const float m0 = mrow[x], m1 = mrow[x + 1];
-          for (int e = 0; e < expo; ++e) {
-            v.x *= m0;
-            v.y *= m1;
-          }
-        }
+    const float* mrow = mask + (int64_t)y * g.W;
+#pragma unroll
+    for (int it = 0; it < IT0; ++it) {
+      const int j = tid + it * MC_WG;
+#pragma unroll
+      for (int q = 0; q < R0; ++q) {
+        const int x = 2 * (j + q * NB0);
+        const bool on = (NB0 >= MC_WG || j < NB0) && x >= g.x0 && x < g.x1;
+        p[it][q] = on ? cmake(row[x], row[x + 1]) : cmake(mean, mean);
+        m[it][q] = (on && expo > 0) ? cmake(mrow[x], mrow[x + 1]) : cmake(on ? 1.f : 0.f, on ? 1.f : 0.f);
+      }
+    }
+  };
+  int s = 0;
+  auto process = [&](int r, cfloat (&p)[IT0][R0], cfloat (&m)[IT0][R0]) {
+    auto load = [&](int, int it, int q) {
+      cfloat v = cmake((p[it][q].x - mean) * rstd, (p[it][q].y - mean) * rstd);
+      const cfloat mm = m[it][q];
+      v.x *= mm.x;
+      v.y *= mm.y;
+      for (int e = 1; e < expo; ++e) {
+        v.x *= mm.x;
+        v.y *= mm.y;
       }
       return v;
     };
-    auto store = [&](int i, cfloat v) { line[lpad(i)] = v; };
-    wg_fft<N, -1>(line, tid, tw_row, 2, load, store);
-    __syncthreads();
+    auto nostore = [](int, cfloat) {};
+    const int res = wg_fft_pp<N, -1, false>(l0, l1, s, tid, T, load, nostore);
+    const cfloat* Z = res ? l1 : l0;
     // real-FFT unpack: X[k] = (Z[k] + conj(Z[N-k]))/2 - i/2 * w^k * (Z[k] - conj(Z[N-k]))
     for (int k = tid; k < g.nkx; k += MC_WG) {
-      const cfloat zk = line[lpad(k & (N - 1))];
-      const cfloat zm = cconj(line[lpad((N - k) & (N - 1))]);
-      const cfloat s = cadd(zk, zm), d = csub(zk, zm);
+      const cfloat zk = Z[lpad(k & (N - 1))];
+      const cfloat zm = cconj(Z[lpad((N - k) & (N - 1))]);
+      const cfloat sm = cadd(zk, zm), d = csub(zk, zm);
       const cfloat w = (k < N) ? tw_row[k] : cmake(-1.f, 0.f);
       const cfloat wd = cmul(w, d);  // -i*wd = (wd.y, -wd.x)
-      stg[k * (RG + 1) + r] = cmake(0.5f * (s.x + wd.y), 0.5f * (s.y - wd.x));
+      stg[k * (RG + 1) + r] = cmake(0.5f * (sm.x + wd.y), 0.5f * (sm.y - wd.x));
     }
-    __syncthreads();
+    s = res ^ 1;  // next row must not start in the line that is still being unpacked
+  };
+  if constexpr (PREFETCH) {
+    issue(0, pxA, mkA);
+    for (int r = 0; r < RG; r += 2) {
+      if (r + 1 < RG) issue(r + 1, pxB, mkB);
+      process(r, pxA, mkA);
+      if (r + 1 < RG) {
+        if (r + 2 < RG) issue(r + 2, pxA, mkA);
+        process(r + 1, pxB, mkB);
+      }
+    }
+  } else {
+    for (int r = 0; r < RG; ++r) {
+      issue(r, pxA, mkA);
+      process(r, pxA, mkA);
+    }
   }
+  __syncthreads();
   cfloat* out = T1 + (int64_t)job * g.nkx * g.ny + (int64_t)grp * RG;
   for (int i = tid; i < g.nkx * RG; i += MC_WG) {
     const int kx = i / RG, r = i - kx * RG;
@@ -177,34 +213,98 @@ __device__ __forceinline__ void cand_merge(float& bv, int& bi, float v, int i) {
 }
 
 // EPI 0: arg-max over the whole map (partials per workgroup); EPI 1: store real rows.
+// Branch and bound for the arg-max (EPI 0): every value of row y obeys
+//   |cc(y,x)| <= |X[0]| + 2 * sum_{k>=1} |X[k]|          (X = T2[.][y], triangle inequality)
+// so a row group whose bound is below a value some other workgroup has already
+// *attained* cannot hold the maximum (nor tie with it) and is skipped; `best[p]` carries
+// that running maximum (monotone atomic max, stale reads only cost skipped work).
+// Groups are visited nearest-to-zero-shift first, where the peak usually is.
+__device__ __forceinline__ int float_order(float f) {  // order-preserving float -> int
+  const int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7fffffff;
+}
+
 template <int LOGN, int EPI>
 __global__ __launch_bounds__(MC_WG) void xc_rows_inv(const cfloat* __restrict__ T2,
+                                                     int* __restrict__ best,
                                                      float* __restrict__ part_val,
                                                      int* __restrict__ part_idx,
                                                      float* __restrict__ out_real,
                                                      const int64_t* __restrict__ out_off,
                                                      int64_t out_stride,
-                                                     const cfloat* __restrict__ tw_row, XcGeom g) {
+                                                     const cfloat* __restrict__ tw_row, XcGeom g,
+                                                     int near, int phase) {
   constexpr int N = 1 << LOGN;
+  constexpr int R0 = FftPlan<N>::radix(0), NB0 = N / R0, IT0 = FftPlan<N>::iters(0);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  cfloat* line = reinterpret_cast<cfloat*>(smem);
-  cfloat* stg = line + lds_len(N);
+  cfloat* l0 = reinterpret_cast<cfloat*>(smem);
+  cfloat* l1 = l0 + lds_len(N);
+  cfloat* stg = l1 + lds_len(N);
   const int tid = threadIdx.x;
-  const int p = blockIdx.y, grp = blockIdx.x;
+  const int p = blockIdx.y;
   const int RG = g.RG;
-  const int ngrp = gridDim.x;
+  const int ngrp = g.H / RG;
+  // phase 0: the `near` groups at each end of the map (small |shift|), evaluated
+  // unconditionally -> best[p]; phase 1: all other groups, with the skip test.
+  int grp = blockIdx.x;
+  if (EPI == 0) grp = phase == 0 ? ((int)blockIdx.x < near ? (int)blockIdx.x : ngrp - 2 * near + (int)blockIdx.x)
+                                 : near + (int)blockIdx.x;
   const cfloat* in = T2 + (int64_t)p * g.nkx * g.H + (int64_t)grp * RG;
+  float bound = 0.f;
   for (int i = tid; i < g.nkx * RG; i += MC_WG) {
     const int kx = i / RG, r = i - kx * RG;
-    stg[kx * (RG + 1) + r] = in[(int64_t)kx * g.H + r];
+    const cfloat v = in[(int64_t)kx * g.H + r];
+    stg[kx * (RG + 1) + r] = v;
+    if (EPI == 0) bound += (kx == 0 ? 1.f : 2.f) * sqrtf(v.x * v.x + v.y * v.y);
   }
+  if constexpr (EPI == 0) {
+    // per-row bounds: element i belongs to row i % RG = tid % RG (RG divides 256), so
+    // lanes with equal lane % RG hold partial sums of the same row
+    for (int off = 32; off >= RG; off >>= 1) bound += __shfl_xor(bound, off);
+    __shared__ float wb[MC_WG / 64][16];
+    __shared__ int skip;
+    if ((tid & 63) < RG) wb[tid >> 6][tid & 63] = bound;
+    __syncthreads();
+    if (tid == 0) {
+      float b = 0.f;
+      for (int r = 0; r < RG; ++r) {
+        float br = 0.f;
+        for (int w = 0; w < MC_WG / 64; ++w) br += wb[w][r];
+        b = fmaxf(b, br);
+      }
+      b = b * 1.0001f + 1e-30f;  // rounding slack of the transform itself
+      skip = phase == 1 &&
+             float_order(b) < __hip_atomic_load(&best[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (skip) {
+        part_val[(int64_t)p * ngrp + grp] = -INFINITY;
+        part_idx[(int64_t)p * ngrp + grp] = 0x7fffffff;
+      }
+    }
+    __syncthreads();
+    if (skip) return;
+  }
+  FftTwiddles<N> T;
+  T.template init<+1>(tid, tw_row, 2);
+  // c2r pack twiddles conj(w^k) for this thread's first-pass elements
+  cfloat wk[IT0][R0];
+#pragma unroll
+  for (int it = 0; it < IT0; ++it)
+#pragma unroll
+    for (int q = 0; q < R0; ++q) {
+      const int j = tid + it * MC_WG;
+      const int k = (NB0 >= MC_WG || j < NB0) ? j + q * NB0 : 0;
+      cfloat w = tw_row[k];
+      w.y = -w.y;
+      wk[it][q] = w;
+    }
   __syncthreads();
   float bv = -INFINITY;
   int bi = 0x7fffffff;
+  int s = 0;
   for (int r = 0; r < RG; ++r) {
     const int y = grp * RG + r;
     // c2r pack: Z[k] = (X[k] + conj(X[N-k])) + i * conj(w^k) * (X[k] - conj(X[N-k]))
-    auto load = [&](int k) {
+    auto load = [&](int k, int it, int q) {
       const int km = N - k;  // in [1, N]
       cfloat xk = (k < g.nkx) ? stg[k * (RG + 1) + r] : cmake(0.f, 0.f);
       cfloat xm = (km < g.nkx) ? cconj(stg[km * (RG + 1) + r]) : cmake(0.f, 0.f);
@@ -212,28 +312,27 @@ __global__ __launch_bounds__(MC_WG) void xc_rows_inv(const cfloat* __restrict__ 
         xk.y = 0.f;
         xm.y = 0.f;
       }
-      const cfloat s = cadd(xk, xm), d = csub(xk, xm);
-      cfloat w = tw_row[k];
-      w.y = -w.y;
-      const cfloat wd = cmul(w, d);  // i*wd = (-wd.y, wd.x)
-      return cmake(s.x - wd.y, s.y + wd.x);
+      const cfloat sm = cadd(xk, xm), d = csub(xk, xm);
+      const cfloat wd = cmul(wk[it][q], d);  // i*wd = (-wd.y, wd.x)
+      return cmake(sm.x - wd.y, sm.y + wd.x);
     };
+    int res;
     if constexpr (EPI == 0) {
       auto store = [&](int n, cfloat v) {
         const int flat = y * g.W + 2 * n;
         cand_merge(bv, bi, v.x, flat);
         cand_merge(bv, bi, v.y, flat + 1);
       };
-      wg_fft<N, +1>(line, tid, tw_row, 2, load, store);
+      res = wg_fft_pp<N, +1, true>(l0, l1, s, tid, T, load, store);
     } else {
       float* orow = out_real + out_off[p] + (int64_t)y * out_stride;
       auto store = [&](int n, cfloat v) {
         orow[2 * n] = v.x;
         orow[2 * n + 1] = v.y;
       };
-      wg_fft<N, +1>(line, tid, tw_row, 2, load, store);
+      res = wg_fft_pp<N, +1, true>(l0, l1, s, tid, T, load, store);
     }
-    __syncthreads();  // line is reused by the next row
+    s = res ^ 1;  // the last pass still reads line[res] while the next row starts
   }
   if constexpr (EPI == 0) {
     for (int off = 32; off > 0; off >>= 1) {
@@ -252,6 +351,7 @@ __global__ __launch_bounds__(MC_WG) void xc_rows_inv(const cfloat* __restrict__ 
       for (int w = 1; w < MC_WG / 64; ++w) cand_merge(bv, bi, wv[w], wi[w]);
       part_val[(int64_t)p * ngrp + grp] = bv;
       part_idx[(int64_t)p * ngrp + grp] = bi;
+      atomicMax(&best[p], float_order(bv));
     }
   }
 }
@@ -369,7 +469,7 @@ static int geom_from(const mc_xc_geom* q, XcGeom* g) {
 }
 
 static size_t rows_lds_bytes(int N, const XcGeom& g) {
-  return sizeof(cfloat) * ((size_t)lds_len(N) + (size_t)g.nkx * (g.RG + 1));
+  return sizeof(cfloat) * (2 * (size_t)lds_len(N) + (size_t)g.nkx * (g.RG + 1));
 }
 
 extern "C" {
@@ -393,8 +493,13 @@ int mc_xc_rows_forward(const float* src, const int64_t* job_off, int64_t row_str
   const size_t lds = rows_lds_bytes(g.W / 2, g);
   if (lds > 160 * 1024) return MC_ERR_ARG;
   dim3 grid(g.ny / g.RG, njobs);
+  static int variant = -1;
+  if (variant < 0) {
+    const char* v = getenv("MC_K1_VARIANT");
+    variant = v ? atoi(v) : 0;
+  }
   MC_DISPATCH_LOG(logn, {
-    auto k = xc_rows_fwd<L>;
+    auto k = variant == 1 ? xc_rows_fwd<L, 1> : xc_rows_fwd<L, 0>;
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, grid, dim3(MC_WG), lds, (hipStream_t)stream, src, job_off, row_stride,
@@ -452,6 +557,7 @@ int mc_fourier_shift_cols_inverse(const void* S, const int* idx, const float* sh
 int mc_xc_rows_inverse_argmax(const void* T2, float* part_val, int* part_idx, int* peaks,
                               float* shifts, const void* tw_row, int npairs, const mc_xc_geom* q,
                               void* stream) {
+  // part_idx holds npairs*(H/RG) candidates followed by npairs running maxima
   XcGeom g;
   int rc = geom_from(q, &g);
   if (rc) return rc;
@@ -461,14 +567,29 @@ int mc_xc_rows_inverse_argmax(const void* T2, float* part_val, int* part_idx, in
   const size_t lds = rows_lds_bytes(g.W / 2, g);
   if (lds > 160 * 1024) return MC_ERR_ARG;
   const int ngrp = g.H / g.RG;
-  dim3 grid(ngrp, npairs);
+  int* best = part_idx + (int64_t)npairs * ngrp;
+  {  // best[p] = order(-inf)
+    const float ninf = -INFINITY;
+    int pat;
+    memcpy(&pat, &ninf, 4);
+    pat = pat >= 0 ? pat : pat ^ 0x7fffffff;
+    hipError_t e = hipMemsetD32Async((hipDeviceptr_t)best, pat, npairs, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  int near = (64 + g.RG - 1) / g.RG;  // groups covering |shift_y| <= 64 px at each end
+  if (2 * near > ngrp) near = ngrp / 2;
   MC_DISPATCH_LOG(logn, {
     auto k = xc_rows_inv<L, 0>;
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, grid, dim3(MC_WG), lds, (hipStream_t)stream, (const cfloat*)T2, part_val,
-                       part_idx, (float*)nullptr, (const int64_t*)nullptr, (int64_t)0,
-                       (const cfloat*)tw_row, g);
+    if (near > 0)
+      hipLaunchKernelGGL(k, dim3(2 * near, npairs), dim3(MC_WG), lds, (hipStream_t)stream,
+                         (const cfloat*)T2, best, part_val, part_idx, (float*)nullptr,
+                         (const int64_t*)nullptr, (int64_t)0, (const cfloat*)tw_row, g, near, 0);
+    if (ngrp - 2 * near > 0)
+      hipLaunchKernelGGL(k, dim3(ngrp - 2 * near, npairs), dim3(MC_WG), lds, (hipStream_t)stream,
+                         (const cfloat*)T2, best, part_val, part_idx, (float*)nullptr,
+                         (const int64_t*)nullptr, (int64_t)0, (const cfloat*)tw_row, g, near, 1);
   });
   rc = mc_check_launch();
   if (rc) return rc;
@@ -493,8 +614,8 @@ int mc_xc_rows_inverse_store(const void* T2, float* out, const int64_t* out_off,
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, grid, dim3(MC_WG), lds, (hipStream_t)stream, (const cfloat*)T2,
-                       (float*)nullptr, (int*)nullptr, out, out_off, out_stride,
-                       (const cfloat*)tw_row, g);
+                       (int*)nullptr, (float*)nullptr, (int*)nullptr, out, out_off, out_stride,
+                       (const cfloat*)tw_row, g, 0, 0);
   });
   return mc_check_launch();
 }

@@ -17,6 +17,19 @@ from ._lib import check, ptr, stream_ptr
 WORKSPACE_BYTES = 2 << 30  # soft cap for one transposed intermediate (T1 / T2)
 
 
+_CONST: dict = {}
+
+
+def _cached(key, build):
+    """Small device-resident index/tap tables, built once per (shape, device)."""
+    v = _CONST.get(key)
+    if v is None:
+        if len(_CONST) > 512:
+            _CONST.clear()
+        v = _CONST[key] = build()
+    return v
+
+
 def _i32(a, device):
     return torch.as_tensor(np.asarray(a, dtype=np.int32), device=device)
 
@@ -86,7 +99,7 @@ def _peaks(S_cur, cur_idx, S_ref, ref_idx, pl, want_nbhd):
     T2 = torch.empty((chunk, g.nkx, g.H, 2), dtype=torch.float32, device=dev)
     ngrp = g.H // g.RG
     pv = torch.empty(chunk * ngrp, dtype=torch.float32, device=dev)
-    pi = torch.empty(chunk * ngrp, dtype=torch.int32, device=dev)
+    pi = torch.empty(chunk * ngrp + chunk, dtype=torch.int32, device=dev)
     st = stream_ptr(dev)
     scale = 1.0 / (g.H * g.W)
     for a in range(0, npairs, chunk):
@@ -114,17 +127,20 @@ def global_shifts(img, reference_frame, pixel_spacing, b_factor, frequency_range
     dev = img.device
     pl = planmod.get_xc_plan(h, w, pixel_spacing, b_factor, frequency_range, dev)
     stats = central_box_stats(img)
-    job_off = torch.arange(t, device=dev, dtype=torch.int64) * (h * w)
+    job_off = _cached(("frame_off", str(dev), t, h, w),
+                      lambda: torch.arange(t, device=dev, dtype=torch.int64) * (h * w))
     S = _forward_spectra(img, job_off, w, None, pl, stats)
     cur = [f for f in range(t) if f != reference_frame]
-    out = torch.zeros((t, 2), dtype=torch.float32, device=dev)
     if not cur:
-        return out
-    cur_idx = _i32(cur, dev)
-    ref_idx = torch.full_like(cur_idx, reference_frame)
+        return torch.zeros((t, 2), dtype=torch.float32, device=dev)
+    cur_idx, ref_idx, scatter = _cached(
+        ("global_pairs", str(dev), t, reference_frame),
+        lambda: (_i32(cur, dev), _i32([reference_frame] * len(cur), dev),
+                 _i64([cur.index(f) if f != reference_frame else len(cur) for f in range(t)], dev)))
     _, shifts, _ = _peaks(S, cur_idx, S, ref_idx, pl, want_nbhd=False)
-    out[cur_idx.long()] = shifts
-    return out
+    # row `len(cur)` of the padded table is the zero shift of the reference frame itself
+    padded = torch.cat([shifts, shifts.new_zeros((1, 2))], dim=0)
+    return padded.index_select(0, scatter)
 
 
 # ------------------------------------------------------------------ a8: patch field
@@ -217,8 +233,13 @@ def spline_lattice(field, ut, uy, ux, grid_type):
     c, nt, nh, nw = field.shape
     tabs = []
     for n, u in ((nt, ut), (nh, uy), (nw, ux)):
-        idx, wts = spline.axis_taps(n, u, grid_type)
-        tabs.append((idx.to(dev), wts.to(dev), int(u.numel())))
+        u = u.detach().to(torch.float32).cpu().contiguous()
+
+        def build(n=n, u=u):
+            idx, wts = spline.axis_taps(n, u, grid_type)
+            return idx.to(dev), wts.to(dev), int(u.numel())
+
+        tabs.append(_cached(("taps", str(dev), n, grid_type, u.numpy().tobytes()), build))
     out = torch.empty((c, tabs[0][2], tabs[1][2], tabs[2][2]), dtype=torch.float32, device=dev)
     f = field.contiguous()
     check(lib.mc_spline_lattice(ptr(f), c, nt, nh, nw, ptr(tabs[0][0]), ptr(tabs[0][1]), tabs[0][2],
@@ -232,8 +253,8 @@ def frame_lattices(field, t, grid_type):
     """(t, 2, 10gh, 10gw) Angstrom lattices, one per frame time linspace(0,1,t)
     (correct_motion.py:57,67-72)."""
     _, _, gh, gw = field.shape
-    lat = spline_lattice(field, torch.linspace(0, 1, steps=t), torch.linspace(0, 1, steps=10 * gh),
-                         torch.linspace(0, 1, steps=10 * gw), grid_type)
+    lin = lambda n: _cached(("linspace", n), lambda: torch.linspace(0, 1, steps=n))
+    lat = spline_lattice(field, lin(t), lin(10 * gh), lin(10 * gw), grid_type)
     return lat.permute(1, 0, 2, 3).contiguous()
 
 

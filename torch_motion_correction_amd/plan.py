@@ -66,7 +66,7 @@ def xc_geometry(h: int, w: int, high: float, radius: float, smoothing: float) ->
     x1 += x1 & 1
     n_line = w // 2
     rg = 16
-    while rg > 1 and 8 * (n_line + (n_line >> 4) + 1 + nkx * (rg + 1)) > LDS_BUDGET:
+    while rg > 1 and 8 * (2 * (n_line + (n_line >> 4) + 1) + nkx * (rg + 1)) > LDS_BUDGET:
         rg //= 2
     rg = min(rg, h)
     y0 -= y0 % rg
