@@ -71,10 +71,27 @@ int mc_xc_rows_forward(const float* src, const int64_t* job_off, int64_t row_str
                        const int* job_expo, const float* mask, const float* mean_rstd, void* T1,
                        const void* tw_row, int njobs, const mc_xc_geom* geom, void* stream);
 
+/* K1 with the normalisation statistics fused in (whole-frame jobs only): samples become
+ * (x - m0[0]) * mask (m0: device float[3] = {provisional mean, 1, 1}); while reading, the
+ * sums of (x-m0) and (x-m0)^2 over the central box rows [hl,hu) x cols [wl,wu) (window
+ * coordinates, inside the mask support, wl/wu even) of every job are accumulated;
+ * afterwards fix = {mean - m0, 1/std} and out3 = {mean, 1/std, std} (unbiased std over
+ * all jobs jointly, utils.py:76-84).  acc: 2 doubles scratch.  Feed `fix` to
+ * mc_xc_cols_forward_fix, which finishes the normalisation by linearity. */
+int mc_xc_rows_forward_stats(const float* src, const int64_t* job_off, int64_t row_stride,
+                             const float* mask, const float* m0, void* T1, const void* tw_row,
+                             int njobs, const mc_xc_geom* geom, int hl, int hu, int wl, int wu,
+                             double* acc, float* fix, float* out3, void* stream);
+
 /* K2.  Column FFT of T1, kept ky rows, times filt (or NULL) -> S[j][kx][kyi].
  * estimate_motion_xc.py:78,98 / :340-346. */
 int mc_xc_cols_forward(const void* T1, const float* filt, void* S, const void* tw_col, int njobs,
                        const mc_xc_geom* geom, void* stream);
+/* K2 with the linear normalisation fix-up: S = filt * fix[1] * (Y - fix[0] * Mhat), Mhat =
+ * pruned spectrum of the mask ([kx][kyi] complex, i.e. K1+K2 of an all-ones window). */
+int mc_xc_cols_forward_fix(const void* T1, const float* filt, void* S, const void* tw_col,
+                           int njobs, const mc_xc_geom* geom, const float* fix, const void* Mhat,
+                           void* stream);
 
 /* K3.  pair p: conj(S_ref[ref_idx[p]]) * S_cur[cur_idx[p]] * scale, inverse column FFT
  * -> T2[p][kx][H].  estimate_motion_xc.py:112-113 / :349-350. */

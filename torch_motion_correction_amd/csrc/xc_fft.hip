@@ -34,12 +34,16 @@ struct XcGeom {
 // Two LDS lines (ping-pong: one barrier per pass), twiddles in registers for the whole
 // row loop, and the next row's samples + mask values already in flight (registers)
 // while the current row is transformed.
-template <int LOGN, int PREFETCH>
+struct XcBox {  // central box of normalize_image (utils.py:76-81) in window coordinates
+  int hl, hu, wl, wu;
+};
+
+template <int LOGN, int PREFETCH, bool STATS>
 __global__ __launch_bounds__(MC_WG) void xc_rows_fwd(
     const float* __restrict__ src, const int64_t* __restrict__ job_off, int64_t row_stride,
     const int* __restrict__ job_expo, const float* __restrict__ mask,
     const float* __restrict__ mean_rstd, cfloat* __restrict__ T1,
-    const cfloat* __restrict__ tw_row, XcGeom g) {
+    const cfloat* __restrict__ tw_row, XcGeom g, XcBox box, double* __restrict__ stats_acc) {
   constexpr int N = 1 << LOGN;  // complex length = W/2
   constexpr int R0 = FftPlan<N>::radix(0), NB0 = N / R0, IT0 = FftPlan<N>::iters(0);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -75,7 +79,25 @@ __global__ __launch_bounds__(MC_WG) void xc_rows_fwd(
     }
   };
   int s = 0;
+  float st_s = 0.f, st_q = 0.f;  // sum and sum of squares of (x - mean_rstd[0]) inside the box
   auto process = [&](int r, cfloat (&p)[IT0][R0], cfloat (&m)[IT0][R0]) {
+    if constexpr (STATS) {
+      const int y = g.y0 + grp * RG + r;
+      if (y >= box.hl && y < box.hu) {
+#pragma unroll
+        for (int it = 0; it < IT0; ++it)
+#pragma unroll
+          for (int q = 0; q < R0; ++q) {
+            const int x = 2 * (tid + it * MC_WG + q * NB0);
+            if ((NB0 >= MC_WG || tid + it * MC_WG < NB0) && x >= box.wl && x < box.wu) {
+              // box.wl/wu are even here (host guarantees), so x+1 is inside too
+              const float a = p[it][q].x - mean, b = p[it][q].y - mean;
+              st_s += a + b;
+              st_q += a * a + b * b;
+            }
+          }
+      }
+    }
     auto load = [&](int, int it, int q) {
       cfloat v = cmake((p[it][q].x - mean) * rstd, (p[it][q].y - mean) * rstd);
       const cfloat mm = m[it][q];
@@ -123,14 +145,57 @@ __global__ __launch_bounds__(MC_WG) void xc_rows_fwd(
     const int kx = i / RG, r = i - kx * RG;
     out[(int64_t)kx * g.ny + r] = stg[kx * (RG + 1) + r];
   }
+  if constexpr (STATS) {
+    double ds = st_s, dq = st_q;
+    for (int off = 32; off > 0; off >>= 1) {
+      ds += __shfl_down(ds, off);
+      dq += __shfl_down(dq, off);
+    }
+    __shared__ double rs[MC_WG / 64], rq[MC_WG / 64];
+    if ((tid & 63) == 0) {
+      rs[tid >> 6] = ds;
+      rq[tid >> 6] = dq;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < MC_WG / 64; ++w) {
+        ds += rs[w];
+        dq += rq[w];
+      }
+      if (ds != 0.0 || dq != 0.0) {
+        atomicAdd(&stats_acc[0], ds);
+        atomicAdd(&stats_acc[1], dq);
+      }
+    }
+  }
+}
+
+// (sum, sumsq) of (x - m0) over `count` samples -> fix = {mean - m0, 1/std},
+// out3 = {mean, 1/std, std}  (unbiased std, as torch.std_mean, utils.py:81)
+__global__ void xc_stats_finalize(const double* __restrict__ acc, double count,
+                                  const float* __restrict__ m0, float* __restrict__ fix,
+                                  float* __restrict__ out3) {
+  const double dm = acc[0] / count;
+  double var = (acc[1] - acc[0] * acc[0] / count) / (count - 1.0);
+  if (var < 0) var = 0;
+  const float stdf = (float)sqrt(var);
+  fix[0] = (float)dm;
+  fix[1] = 1.0f / stdf;
+  out3[0] = (float)((double)m0[0] + dm);
+  out3[1] = 1.0f / stdf;
+  out3[2] = stdf;
 }
 
 // ------------------------------------------------------------------ K2: columns forward
+// fix (optional): {dmean, rstd} and Mhat = pruned spectrum of the mask: the spectrum of
+// ((x - m0) - dmean) * rstd * mask is (Y - dmean * Mhat) * rstd by linearity.
 template <int LOGH>
 __global__ __launch_bounds__(MC_WG) void xc_cols_fwd(const cfloat* __restrict__ T1,
                                                      const float* __restrict__ filt,
                                                      cfloat* __restrict__ S,
-                                                     const cfloat* __restrict__ tw_col, XcGeom g) {
+                                                     const cfloat* __restrict__ tw_col, XcGeom g,
+                                                     const float* __restrict__ fix,
+                                                     const cfloat* __restrict__ Mhat) {
   constexpr int H = 1 << LOGH;
   __shared__ __attribute__((aligned(16))) cfloat line[lds_len(H)];
   const int tid = threadIdx.x;
@@ -139,6 +204,8 @@ __global__ __launch_bounds__(MC_WG) void xc_cols_fwd(const cfloat* __restrict__ 
   const int nky = g.kyp + g.kyn;
   cfloat* out = S + ((int64_t)job * g.nkx + kx) * nky;
   const float* f = filt ? filt + (int64_t)kx * nky : nullptr;
+  const cfloat* mh = fix ? Mhat + (int64_t)kx * nky : nullptr;
+  const float dmean = fix ? fix[0] : 0.f, rstd = fix ? fix[1] : 1.f;
   auto load = [&](int y) {
     const int yy = y - g.y0;
     return (yy >= 0 && yy < g.ny) ? col[yy] : cmake(0.f, 0.f);
@@ -147,7 +214,13 @@ __global__ __launch_bounds__(MC_WG) void xc_cols_fwd(const cfloat* __restrict__ 
     int kyi = -1;
     if (ky < g.kyp) kyi = ky;
     else if (ky >= H - g.kyn) kyi = ky - (H - g.kyn) + g.kyp;
-    if (kyi >= 0) out[kyi] = f ? cscale(v, f[kyi]) : v;
+    if (kyi >= 0) {
+      if (fix) {
+        const cfloat m = mh[kyi];
+        v = cmake((v.x - dmean * m.x) * rstd, (v.y - dmean * m.y) * rstd);
+      }
+      out[kyi] = f ? cscale(v, f[kyi]) : v;
+    }
   };
   wg_fft<H, -1>(line, tid, tw_col, 1, load, store);
 }
@@ -481,10 +554,10 @@ int mc_xc_rows_lds_bytes(const mc_xc_geom* q) {
   return (int)rows_lds_bytes(g.W / 2, g);
 }
 
-int mc_xc_rows_forward(const float* src, const int64_t* job_off, int64_t row_stride,
-                       const int* job_expo, const float* mask, const float* mean_rstd,
-                       void* T1, const void* tw_row, int njobs, const mc_xc_geom* q,
-                       void* stream) {
+static int rows_forward_impl(const float* src, const int64_t* job_off, int64_t row_stride,
+                             const int* job_expo, const float* mask, const float* mean_rstd,
+                             void* T1, const void* tw_row, int njobs, const mc_xc_geom* q,
+                             const XcBox* box, double* stats_acc, void* stream) {
   XcGeom g;
   int rc = geom_from(q, &g);
   if (rc) return rc;
@@ -498,26 +571,62 @@ int mc_xc_rows_forward(const float* src, const int64_t* job_off, int64_t row_str
     const char* v = getenv("MC_K1_VARIANT");
     variant = v ? atoi(v) : 0;
   }
+  XcBox b = box ? *box : XcBox{0, 0, 0, 0};
   MC_DISPATCH_LOG(logn, {
-    auto k = variant == 1 ? xc_rows_fwd<L, 1> : xc_rows_fwd<L, 0>;
+    auto k = stats_acc ? xc_rows_fwd<L, 0, true> : (variant == 1 ? xc_rows_fwd<L, 1, false> : xc_rows_fwd<L, 0, false>);
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, grid, dim3(MC_WG), lds, (hipStream_t)stream, src, job_off, row_stride,
-                       job_expo, mask, mean_rstd, (cfloat*)T1, (const cfloat*)tw_row, g);
+                       job_expo, mask, mean_rstd, (cfloat*)T1, (const cfloat*)tw_row, g, b, stats_acc);
   });
+  return mc_check_launch();
+}
+
+int mc_xc_rows_forward(const float* src, const int64_t* job_off, int64_t row_stride,
+                       const int* job_expo, const float* mask, const float* mean_rstd,
+                       void* T1, const void* tw_row, int njobs, const mc_xc_geom* q,
+                       void* stream) {
+  return rows_forward_impl(src, job_off, row_stride, job_expo, mask, mean_rstd, T1, tw_row, njobs, q,
+                           nullptr, nullptr, stream);
+}
+
+int mc_xc_rows_forward_stats(const float* src, const int64_t* job_off, int64_t row_stride,
+                             const float* mask, const float* m0, void* T1, const void* tw_row,
+                             int njobs, const mc_xc_geom* q, int hl, int hu, int wl, int wu,
+                             double* acc, float* fix, float* out3, void* stream) {
+  if (!m0 || !acc || !fix || !out3 || !q) return MC_ERR_ARG;
+  if (hl < q->y0 || hu > q->y0 + q->ny || wl < q->x0 || wu > q->x1 || (wl & 1) || (wu & 1) ||
+      hl >= hu || wl >= wu)
+    return MC_ERR_ARG;  // the box must lie inside the region K1 reads
+  hipError_t e = hipMemsetAsync(acc, 0, 2 * sizeof(double), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  XcBox box{hl, hu, wl, wu};
+  int rc = rows_forward_impl(src, job_off, row_stride, nullptr, mask, m0, T1, tw_row, njobs, q, &box,
+                             acc, stream);
+  if (rc) return rc;
+  const double count = (double)njobs * (hu - hl) * (wu - wl);
+  hipLaunchKernelGGL(xc_stats_finalize, dim3(1), dim3(1), 0, (hipStream_t)stream, acc, count, m0, fix,
+                     out3);
   return mc_check_launch();
 }
 
 int mc_xc_cols_forward(const void* T1, const float* filt, void* S, const void* tw_col, int njobs,
                        const mc_xc_geom* q, void* stream) {
+  return mc_xc_cols_forward_fix(T1, filt, S, tw_col, njobs, q, nullptr, nullptr, stream);
+}
+
+int mc_xc_cols_forward_fix(const void* T1, const float* filt, void* S, const void* tw_col,
+                           int njobs, const mc_xc_geom* q, const float* fix, const void* Mhat,
+                           void* stream) {
   XcGeom g;
   int rc = geom_from(q, &g);
   if (rc) return rc;
-  if (!T1 || !S || !tw_col || njobs < 1) return MC_ERR_ARG;
+  if (!T1 || !S || !tw_col || njobs < 1 || (fix && !Mhat)) return MC_ERR_ARG;
   dim3 grid(g.nkx, njobs);
   MC_DISPATCH_LOG(mc_ilog2(g.H), {
     hipLaunchKernelGGL(xc_cols_fwd<L>, grid, dim3(MC_WG), 0, (hipStream_t)stream,
-                       (const cfloat*)T1, filt, (cfloat*)S, (const cfloat*)tw_col, g);
+                       (const cfloat*)T1, filt, (cfloat*)S, (const cfloat*)tw_col, g, fix,
+                       (const cfloat*)Mhat);
   });
   return mc_check_launch();
 }

@@ -120,16 +120,56 @@ def _peaks(S_cur, cur_idx, S_ref, ref_idx, pl, want_nbhd):
 # ------------------------------------------------------------------ a1: global shifts
 
 
+def mask_spectrum(pl, dev):
+    """Pruned spectrum of the plan's mask, (nkx, nky, 2): K1+K2 of an all-ones window.
+    Built once per plan; used by the fused-statistics path (normalisation by linearity)."""
+    if getattr(pl, "mhat", None) is None:
+        g = pl.geom
+        ones = torch.ones((g.H, g.W), dtype=torch.float32, device=dev)
+        off = torch.zeros(1, dtype=torch.int64, device=dev)
+        pl.mhat = _forward_spectra(ones, off, g.W, None, pl, None, use_filter=False)[0].contiguous()
+    return pl.mhat
+
+
+def _global_spectra(img, pl):
+    """Filtered pruned spectra of all frames, (t, nkx, nky, 2), with normalize_image's
+    statistics gathered inside K1 whenever the central box lies in the region K1 reads
+    (always for near-square frames); otherwise a separate statistics pass."""
+    lib = _lib.load()
+    t, h, w = img.shape
+    dev, g = img.device, pl.geom
+    hl, hu, wl, wu = int(0.25 * h), int(0.75 * h), int(0.25 * w), int(0.75 * w)
+    job_off = _cached(("frame_off", str(dev), t, h, w),
+                      lambda: torch.arange(t, device=dev, dtype=torch.int64) * (h * w))
+    fused = (hl >= g.y0 and hu <= g.y0 + g.ny and wl >= g.x0 and wu <= g.x1 and wl % 2 == 0
+             and wu % 2 == 0 and hu > hl and wu > wl)
+    if not fused:
+        return _forward_spectra(img, job_off, w, None, pl, central_box_stats(img))
+    st = stream_ptr(dev)
+    mhat = mask_spectrum(pl, dev)
+    # provisional mean m0 (frame 0's box) keeps the linear fix-up free of cancellation
+    m0 = torch.cat([central_box_stats(img[:1])[:1], _cached(("ones2", str(dev)),
+                   lambda: torch.ones(2, dtype=torch.float32, device=dev))])
+    acc = torch.empty(2, dtype=torch.float64, device=dev)
+    fix = torch.empty(2, dtype=torch.float32, device=dev)
+    out3 = torch.empty(3, dtype=torch.float32, device=dev)
+    T1 = torch.empty((t, g.nkx, g.ny, 2), dtype=torch.float32, device=dev)
+    S = torch.empty((t, g.nkx, g.nky, 2), dtype=torch.float32, device=dev)
+    check(lib.mc_xc_rows_forward_stats(ptr(img), ptr(job_off), w, ptr(pl.mask), ptr(m0), ptr(T1),
+                                       ptr(pl.tw_row), t, g, hl, hu, wl, wu, ptr(acc), ptr(fix),
+                                       ptr(out3), st), "mc_xc_rows_forward_stats")
+    check(lib.mc_xc_cols_forward_fix(ptr(T1), ptr(pl.filt), ptr(S), ptr(pl.tw_col), t, g, ptr(fix),
+                                     ptr(mhat), st), "mc_xc_cols_forward_fix")
+    return S
+
+
 def global_shifts(img, reference_frame, pixel_spacing, b_factor, frequency_range):
     """Integer-pixel (t,2) shifts of every frame against `reference_frame`
     (estimate_motion_xc.py:57-123); the reference frame's row is exactly zero."""
     t, h, w = img.shape
     dev = img.device
     pl = planmod.get_xc_plan(h, w, pixel_spacing, b_factor, frequency_range, dev)
-    stats = central_box_stats(img)
-    job_off = _cached(("frame_off", str(dev), t, h, w),
-                      lambda: torch.arange(t, device=dev, dtype=torch.int64) * (h * w))
-    S = _forward_spectra(img, job_off, w, None, pl, stats)
+    S = _global_spectra(img, pl)
     cur = [f for f in range(t) if f != reference_frame]
     if not cur:
         return torch.zeros((t, 2), dtype=torch.float32, device=dev)

@@ -96,6 +96,7 @@ class XcPlan:
     tw_col: torch.Tensor  # (H, 2)
     low: float
     high: float
+    mhat: object = None  # pruned spectrum of the mask (engine.mask_spectrum), built lazily
 
 
 _PLANS: dict = {}
