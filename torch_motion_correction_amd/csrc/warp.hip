@@ -584,6 +584,187 @@ __global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES, RIGID_MINW) void warp_rig
 }
 #pragma clang fp contract(off)
 
+#pragma clang fp contract(fast)
+// ------------------------------------------------------------------ rigid warp, LDS-DMA
+// Same mathematics as warp_rigid; the 36 x 272 input window of a tile goes HBM -> LDS by
+// `global_load_lds_dwordx4` (no VGPR staging, row-major image), double-buffered so the
+// DMA of frame f+1 runs under the arithmetic of frame f with ONE barrier per frame.  A lane
+// reads its 8-float window as three aligned 16-byte LDS reads; the window's misalignment
+// m = (x_tile + Sx - 1) mod 4 is frame-uniform, so the tap selection is resolved at
+// compile time in four specialisations of the strip body.  Columns outside the image
+// (border padding = clipped tap coordinate) are patched in LDS for edge tiles only.
+// Requires w % 4 == 0 and 16-byte aligned frames (host checks; else warp_rigid).
+#define RD_QUADS_PAD (((RIGID_NQ + 63) / 64) * 64)  // DMA granule: 64 lanes x 16 B
+typedef __attribute__((address_space(3))) void* lds_vptr;
+
+template <bool WRITE_FRAMES, bool WRITE_SUM, int M>
+__device__ __forceinline__ void rigid_strip_dma(const RigidArgs& a, const float4* tile, int f,
+                                                int y0, int x0, int wave, int lane, float wyv,
+                                                const float (&wx)[5][4],
+                                                float (&acc)[RIGID_ROWS][4]) {
+  const int h = a.h, w = a.w;
+  const float4* wrow = tile + (wave * RIGID_ROWS) * RIGID_QUADS + lane;
+  float H[5][4];
+#pragma unroll
+  for (int rr = 0; rr < RIGID_ROWS + 4; ++rr) {
+    if ((rr & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+    const float4 q0 = wrow[rr * RIGID_QUADS], q1 = wrow[rr * RIGID_QUADS + 1];
+    float4 q2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (M > 0) q2 = wrow[rr * RIGID_QUADS + 2];
+    const float e[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+    float* Hn = H[rr % 5];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      Hn[k] = (((wx[0][k] * e[M + k] + wx[1][k] * e[M + k + 1]) + wx[2][k] * e[M + k + 2]) +
+               wx[3][k] * e[M + k + 3]) + wx[4][k] * e[M + k + 4];
+    if (rr >= 4) {
+      const int ro = rr - 4;
+      const int yo = y0 + ro;
+      float wy[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+        wy[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wyv), ro * 5 + i));
+      float o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        o[k] = (((wy[0] * H[(ro + 0) % 5][k] + wy[1] * H[(ro + 1) % 5][k]) +
+                 wy[2] * H[(ro + 2) % 5][k]) + wy[3] * H[(ro + 3) % 5][k]) +
+               wy[4] * H[(ro + 4) % 5][k];
+      if (yo < h && x0 < w) {
+        if (WRITE_FRAMES)
+          *reinterpret_cast<float4*>(a.out_frames + (int64_t)f * h * w + (int64_t)yo * w + x0) =
+              make_float4(o[0], o[1], o[2], o[3]);
+        if (WRITE_SUM) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[ro][k] += o[k];
+        }
+      }
+    }
+  }
+}
+
+template <bool WRITE_FRAMES, bool WRITE_SUM>
+__global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES) void warp_rigid_dma(RigidArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_rd[];
+  float4* const b0 = reinterpret_cast<float4*>(smem_rd);
+  float4* const b1 = b0 + RD_QUADS_PAD;
+  const int nt = a.tiles_x * a.tiles_y;
+  const int b = blockIdx.x;
+  int tile = b;
+  if ((nt & 7) == 0) tile = (b & 7) * (nt >> 3) + (b >> 3);  // one band of tile rows per XCD
+  const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
+  const int h = a.h, w = a.w;
+  const int lane = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int tid = wave * RIGID_LANES + lane;
+  const int xt = txi * (RIGID_LANES * 4);
+  const int yt = tyi * (RIGID_WAVES * RIGID_ROWS);
+  const int x0 = xt + lane * 4;
+  const int y0 = yt + wave * RIGID_ROWS;
+  const int64_t hw = (int64_t)h * w;
+  float acc[RIGID_ROWS][4];
+#pragma unroll
+  for (int r = 0; r < RIGID_ROWS; ++r)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[r][k] = 0.f;
+  const int f_lo = a.frames_in_grid ? (int)blockIdx.y : 0;
+  const int f_hi = a.frames_in_grid ? f_lo + 1 : a.nframes;
+
+  // DMA of one frame's window into `dst`: granule i = quads [64 i, 64 i + 64)
+  auto dma = [&](int f, float4* dst) {
+    const float* fr = a.frames + (int64_t)f * hw;
+    const int Sy = a.S[2 * f], Sx = a.S[2 * f + 1];
+    const int ax = (xt + Sx - 1) & ~3;
+    for (int i = wave; i < RD_QUADS_PAD / 64; i += RIGID_WAVES) {
+      int q = i * 64 + lane;
+      q = q < RIGID_NQ ? q : RIGID_NQ - 1;  // tail lanes re-load the last quad into the pad
+      const int tr = q / RIGID_QUADS, qc = q - tr * RIGID_QUADS;
+      int r = yt + Sy - 1 + tr;
+      r = r < 0 ? 0 : (r > h - 1 ? h - 1 : r);
+      int c = ax + 4 * qc;
+      c = c < 0 ? 0 : (c > w - 4 ? w - 4 : c);  // whole quads: inside or clamped (patched later)
+      __builtin_amdgcn_global_load_lds(fr + (int64_t)r * w + c, (lds_vptr)(dst + i * 64), 16, 0, 0);
+    }
+  };
+  // border padding for edge tiles: element at column c outside [0,w) := element at the
+  // clipped column, which lies inside the same tile row
+  auto patch = [&](int f, float4* t4) {
+    const int Sx = a.S[2 * f + 1];
+    const int ax = (xt + Sx - 1) & ~3;
+    if (ax >= 0 && ax + 4 * RIGID_QUADS <= w) return false;
+    float* t = reinterpret_cast<float*>(t4);
+    for (int i = tid; i < RIGID_TROWS * 4 * RIGID_QUADS; i += RIGID_LANES * RIGID_WAVES) {
+      const int tr = i / (4 * RIGID_QUADS), e = i - tr * (4 * RIGID_QUADS);
+      const int c = ax + e;
+      if (c < 0 || c > w - 1) {
+        const int cc = c < 0 ? 0 : w - 1;
+        // the quad holding column cc was loaded at its own (clamped == true) address
+        int qsrc = (cc & ~3) - ax;  // tile-relative element index of that quad's first float
+        qsrc = qsrc < 0 ? 0 : (qsrc > 4 * (RIGID_QUADS - 1) ? 4 * (RIGID_QUADS - 1) : qsrc);
+        t[tr * 4 * RIGID_QUADS + e] = t[tr * 4 * RIGID_QUADS + qsrc + (cc & 3)];
+      }
+    }
+    return true;
+  };
+
+  float wx[5][4], wxn[5][4];
+  float wyv = 0.f, wyvn = 0.f;
+  auto load_weights = [&](int f, float (&W5)[5][4], float& Wv) {
+    Wv = 0.f;
+    const int64_t idx = (int64_t)y0 * 5 + lane;
+    if (lane < 5 * RIGID_ROWS && idx < (int64_t)h * 5) Wv = a.Wy[(int64_t)f * 5 * h + idx];
+    const float* Wx = a.Wx + (int64_t)f * 5 * w + x0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (x0 < w) t = *reinterpret_cast<const float4*>(Wx + (int64_t)j * w);
+      W5[j][0] = t.x; W5[j][1] = t.y; W5[j][2] = t.z; W5[j][3] = t.w;
+    }
+  };
+
+  load_weights(f_lo, wx, wyv);
+  dma(f_lo, b0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (patch(f_lo, b0)) __syncthreads();
+  int cur = 0;
+  for (int f = f_lo; f < f_hi; ++f) {
+    if (f + 1 < f_hi) dma(f + 1, cur ? b0 : b1);
+    const int m = (xt + a.S[2 * f + 1] - 1) & 3;
+    const float4* t = cur ? b1 : b0;
+    switch (m) {
+      case 0: rigid_strip_dma<WRITE_FRAMES, WRITE_SUM, 0>(a, t, f, y0, x0, wave, lane, wyv, wx, acc); break;
+      case 1: rigid_strip_dma<WRITE_FRAMES, WRITE_SUM, 1>(a, t, f, y0, x0, wave, lane, wyv, wx, acc); break;
+      case 2: rigid_strip_dma<WRITE_FRAMES, WRITE_SUM, 2>(a, t, f, y0, x0, wave, lane, wyv, wx, acc); break;
+      default: rigid_strip_dma<WRITE_FRAMES, WRITE_SUM, 3>(a, t, f, y0, x0, wave, lane, wyv, wx, acc); break;
+    }
+    if (f + 1 < f_hi) {
+      load_weights(f + 1, wxn, wyvn);  // ordinary loads last: their wait also retires the DMA
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // DMA of f+1 landed for every wave; everyone is done with buf[cur]
+      cur ^= 1;
+      if (patch(f + 1, cur ? b1 : b0)) __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wx[j][k] = wxn[j][k];
+      wyv = wyvn;
+    }
+  }
+  if (WRITE_SUM && x0 < w) {
+#pragma unroll
+    for (int ro = 0; ro < RIGID_ROWS; ++ro) {
+      const int yo = y0 + ro;
+      if (yo < h) {
+        float* dst = a.out_sum + (int64_t)yo * w + x0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[k] += acc[ro][k];
+      }
+    }
+  }
+}
+#pragma clang fp contract(off)
+
 // get_pixel_shifts (correct_motion.py:132-185) for one lattice: out (h, w, 2) px.
 __global__ void warp_pixel_shifts(const float* __restrict__ etab, const int* __restrict__ ytap,
                                   const float* __restrict__ ycoef, int h, int w, int GH,
@@ -741,6 +922,27 @@ int mc_warp_rigid(const float* frames, int nframes, int h, int w, const float* s
   a.tiles_y = (h + RIGID_WAVES * RIGID_ROWS - 1) / (RIGID_WAVES * RIGID_ROWS);
   a.frames_in_grid = out_sum ? 0 : 1;  // without the fused sum every frame is its own block
   dim3 grid(a.tiles_x * a.tiles_y, a.frames_in_grid ? nframes : 1), block(RIGID_LANES, RIGID_WAVES);
+  static int use_dma = -1;
+  if (use_dma < 0) {
+    const char* v = getenv("MC_RIGID_DMA");
+    use_dma = v ? atoi(v) : 1;
+  }
+  const bool dma_ok = use_dma && (w % 4 == 0) && ((((uintptr_t)frames) & 15) == 0) &&
+                      (!out_frames || ((((uintptr_t)out_frames) & 15) == 0));
+  if (dma_ok) {
+    const size_t lds = 2 * (size_t)RD_QUADS_PAD * 16;
+#define MC_RD_LAUNCH(F, S)                                                                        \
+  do {                                                                                            \
+    auto k = warp_rigid_dma<F, S>;                                                                \
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(k, grid, block, lds, s, a);                                                \
+  } while (0)
+    if (out_frames && out_sum) MC_RD_LAUNCH(true, true);
+    else if (out_frames) MC_RD_LAUNCH(true, false);
+    else MC_RD_LAUNCH(false, true);
+#undef MC_RD_LAUNCH
+    return mc_check_launch();
+  }
   if (out_frames && out_sum) hipLaunchKernelGGL((warp_rigid<true, true>), grid, block, 0, s, a);
   else if (out_frames) hipLaunchKernelGGL((warp_rigid<true, false>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((warp_rigid<false, true>), grid, block, 0, s, a);

@@ -51,8 +51,10 @@ __global__ __launch_bounds__(MC_WG) void xc_rows_fwd(
   cfloat* l1 = l0 + lds_len(N);
   cfloat* stg = l1 + lds_len(N);
   const int tid = threadIdx.x;
-  const int job = blockIdx.y;
-  const int grp = blockIdx.x;
+  // job is the fastest grid dimension: the workgroups that share a row group's mask rows
+  // (one per job) are dispatched together and find them in L2
+  const int job = blockIdx.x;
+  const int grp = blockIdx.y;
   const int RG = g.RG;
   const float mean = mean_rstd ? mean_rstd[0] : 0.f;
   const float rstd = mean_rstd ? mean_rstd[1] : 1.f;
@@ -565,7 +567,7 @@ static int rows_forward_impl(const float* src, const int64_t* job_off, int64_t r
   const int logn = mc_ilog2(g.W) - 1;
   const size_t lds = rows_lds_bytes(g.W / 2, g);
   if (lds > 160 * 1024) return MC_ERR_ARG;
-  dim3 grid(g.ny / g.RG, njobs);
+  dim3 grid(njobs, g.ny / g.RG);
   static int variant = -1;
   if (variant < 0) {
     const char* v = getenv("MC_K1_VARIANT");
