@@ -66,13 +66,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # MC_BENCH_BACKEND / MC_BENCH_ONE_DEVICE exist only to rehearse the multi-rank control
+    # path on a single-GPU box (gloo, every rank on cuda:0); the driver uses the defaults.
+    backend = os.environ.get("MC_BENCH_BACKEND", "nccl")
+    one_device = os.environ.get("MC_BENCH_ONE_DEVICE", "0") == "1"
+    dev = torch.device("cuda", 0 if (world == 1 or one_device) else local)
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
 
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    dev = torch.device("cuda", local if world > 1 else 0)
-    torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import torch_motion_correction_amd as mc
     from torch_motion_correction_amd import engine
@@ -111,7 +117,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

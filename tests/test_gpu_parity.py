@@ -411,3 +411,66 @@ def test_full_size_warp_properties(mc, big_stack, dev):
     sy, sx = int(field[0, f, 0, 0]), int(field[1, f, 0, 0])
     assert torch.allclose(frames[f, 1000:1016, 2000:2016].cpu(),
                           stack[f, 1000 + sy : 1016 + sy, 2000 + sx : 2016 + sx].cpu(), atol=5e-3)
+
+
+# ------------------------------------------------------------------ round-1 additions
+
+
+def test_fused_statistics_match_separate_pass(dev):
+    """K1's in-flight sums + linear fix-up in K2 == separate statistics pass + direct
+    normalisation (both against the oracle's normalize_image numbers)."""
+    from torch_motion_correction_amd import engine, plan
+
+    g = torch.Generator().manual_seed(12)
+    img = (torch.randn(4, 256, 256, generator=g) * 2.5 + 40.0)  # |mean| >> std on purpose
+    d = img.to(dev)
+    pl = plan.get_xc_plan(256, 256, 1.0, 500.0, (300, 10), dev)
+    fused = torch.view_as_complex(engine._global_spectra(d, pl).cpu())
+    off = torch.arange(4, device=dev, dtype=torch.int64) * (256 * 256)
+    sep = torch.view_as_complex(engine._forward_spectra(d, off, 256, None, pl, engine.central_box_stats(d)).cpu())
+    assert float((fused - sep).abs().max() / sep.abs().max()) <= 2e-5
+    st, _, _ = drift_stack(6, 512, 512, seed=5)
+    import torch_motion_correction_amd as m
+
+    assert torch.equal(m.estimate_global_motion((st * 3 + 100).to(dev), 1.0).cpu(),
+                       oracle.estimate_global_motion(st * 3 + 100, 1.0))
+
+
+def test_large_shifts_beyond_the_near_window(mc, dev):
+    """Peaks far from zero shift (|dy| up to 200 px, negative and positive) must be found
+    by the second, bounded phase of the arg-max."""
+    g = torch.Generator().manual_seed(77)
+    base = torch.randn(512 + 512, 512 + 512, generator=g)
+    offs = [(0, 0), (200, -150), (-180, 90), (100, 230), (-70, -240)]
+    st = torch.stack([base[256 - dy : 768 - dy, 256 - dx : 768 - dx] + 0.5 * torch.randn(512, 512, generator=g)
+                      for dy, dx in offs])
+    got = mc.estimate_global_motion(st.to(dev), 1.0, reference_frame=0).cpu()
+    ref = oracle.estimate_global_motion(st, 1.0, reference_frame=0)
+    assert torch.equal(got, ref)
+    assert got[0, :, 0, 0].tolist() == [float(o[0]) for o in offs]
+    assert got[1, :, 0, 0].tolist() == [float(o[1]) for o in offs]
+
+
+def test_pure_noise_has_no_peak_and_still_matches(mc, dev):
+    """Nothing can be skipped by the bound here; the (arbitrary) arg-max must still agree."""
+    g = torch.Generator().manual_seed(123)
+    st = torch.randn(4, 256, 256, generator=g)
+    got = mc.estimate_global_motion(st.to(dev), 1.0).cpu()
+    ref, ccs = oracle.estimate_global_motion(st, 1.0, return_cc=True)
+    for f, cc in ccs.items():  # only compare where the oracle's own maximum is not a near-tie
+        top = torch.topk(cc.flatten(), 2).values
+        if float(top[0] - top[1]) > 1e-5 * float(top[0].abs()):
+            assert torch.equal(got[:, f], ref[:, f])
+
+
+@pytest.mark.parametrize("shape", [(3, 130, 250), (2, 96, 134)])
+def test_rigid_warp_odd_widths(mc, dev, shape):
+    """w % 4 != 0 takes the register-tile rigid kernel (no LDS-DMA); edge tiles everywhere."""
+    g = torch.Generator().manual_seed(sum(shape))
+    img = torch.randn(*shape, generator=g)
+    fld = torch.randn(2, shape[0], 1, 1, generator=g) * 6
+    got = mc.correct_motion(img.to(dev), fld.to(dev), 1.2)
+    ref = oracle.correct_motion(img, fld, 1.2)
+    assert_frames_close(got, ref, knife_edge_mask(img, fld, 1.2, "catmull_rom", eps=2e-3), max_excluded=0.05)
+    total = mc.motion_correct_sum(img.to(dev), fld.to(dev), 1.2).cpu()
+    assert float((total - got.cpu().sum(0)).abs().max()) <= 1e-4
