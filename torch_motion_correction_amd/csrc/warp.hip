@@ -643,11 +643,12 @@ __device__ __forceinline__ void rigid_strip_dma(const RigidArgs& a, const float4
   }
 }
 
-template <bool WRITE_FRAMES, bool WRITE_SUM>
-__global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES) void warp_rigid_dma(RigidArgs a) {
+template <bool WRITE_FRAMES, bool WRITE_SUM, int NBUF>
+__global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES, NBUF == 1 ? ((WRITE_FRAMES && WRITE_SUM) ? 3 : 4) : 2)
+void warp_rigid_dma(RigidArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_rd[];
   float4* const b0 = reinterpret_cast<float4*>(smem_rd);
-  float4* const b1 = b0 + RD_QUADS_PAD;
+  float4* const b1 = NBUF == 2 ? b0 + RD_QUADS_PAD : b0;
   const int nt = a.tiles_x * a.tiles_y;
   const int b = blockIdx.x;
   int tile = b;
@@ -729,7 +730,7 @@ __global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES) void warp_rigid_dma(Rigid
   if (patch(f_lo, b0)) __syncthreads();
   int cur = 0;
   for (int f = f_lo; f < f_hi; ++f) {
-    if (f + 1 < f_hi) dma(f + 1, cur ? b0 : b1);
+    if (NBUF == 2 && f + 1 < f_hi) dma(f + 1, cur ? b0 : b1);
     const int m = (xt + a.S[2 * f + 1] - 1) & 3;
     const float4* t = cur ? b1 : b0;
     switch (m) {
@@ -739,16 +740,27 @@ __global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES) void warp_rigid_dma(Rigid
       default: rigid_strip_dma<WRITE_FRAMES, WRITE_SUM, 3>(a, t, f, y0, x0, wave, lane, wyv, wx, acc); break;
     }
     if (f + 1 < f_hi) {
-      load_weights(f + 1, wxn, wyvn);  // ordinary loads last: their wait also retires the DMA
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();  // DMA of f+1 landed for every wave; everyone is done with buf[cur]
-      cur ^= 1;
-      if (patch(f + 1, cur ? b1 : b0)) __syncthreads();
+      if constexpr (NBUF == 1) {
+        // single buffer, 4 workgroups per CU: other workgroups cover this one's latency,
+        // so nothing is double-buffered here (registers are the scarce resource)
+        __syncthreads();  // everyone must be done reading before the tile is refilled
+        dma(f + 1, b0);
+        load_weights(f + 1, wx, wyv);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (patch(f + 1, b0)) __syncthreads();
+      } else {
+        load_weights(f + 1, wxn, wyvn);  // ordinary loads last: their wait also retires the DMA
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // DMA of f+1 landed for every wave; everyone is done with buf[cur]
+        cur ^= 1;
+        if (patch(f + 1, cur ? b1 : b0)) __syncthreads();
 #pragma unroll
-      for (int j = 0; j < 5; ++j)
+        for (int j = 0; j < 5; ++j)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) wx[j][k] = wxn[j][k];
-      wyv = wyvn;
+          for (int k = 0; k < 4; ++k) wx[j][k] = wxn[j][k];
+        wyv = wyvn;
+      }
     }
   }
   if (WRITE_SUM && x0 < w) {
@@ -930,10 +942,15 @@ int mc_warp_rigid(const float* frames, int nframes, int h, int w, const float* s
   const bool dma_ok = use_dma && (w % 4 == 0) && ((((uintptr_t)frames) & 15) == 0) &&
                       (!out_frames || ((((uintptr_t)out_frames) & 15) == 0));
   if (dma_ok) {
-    const size_t lds = 2 * (size_t)RD_QUADS_PAD * 16;
+    static int nbuf = -1;
+    if (nbuf < 0) {
+      const char* v = getenv("MC_RIGID_NBUF");
+      nbuf = v ? atoi(v) : 1;  // single buffer: 3-4 workgroups/CU beat 2 double-buffered ones
+    }
+    const size_t lds = (size_t)(nbuf == 1 ? 1 : 2) * RD_QUADS_PAD * 16;
 #define MC_RD_LAUNCH(F, S)                                                                        \
   do {                                                                                            \
-    auto k = warp_rigid_dma<F, S>;                                                                \
+    auto k = nbuf == 1 ? warp_rigid_dma<F, S, 1> : warp_rigid_dma<F, S, 2>;                        \
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(k, grid, block, lds, s, a);                                                \
   } while (0)
