@@ -117,9 +117,13 @@ int mc_xc_peak_neighbourhood(const void* T2, const int* peaks, float* nb, const 
 
 /* Reference spectra for reference_strategy="mean_except_current"
  * (estimate_motion_xc.py:310-328 + the in-place mask aliasing):
- * REF[f][g] = inv_count * sum_{o != f} (table[f*t+o] ? V[o][g] : U[o][g]),
- * spectra of `len` complex values, g in [0,npatch).  table: t*t bytes (device). */
-int mc_xc_ref_mean_except_current(const void* U, const void* V, const uint8_t* table, void* REF,
+ * REF[f][g] = inv_count * sum_{o != f} (o in S_f ? V[o][g] : U[o][g]), spectra of `len`
+ * complex values, g in [0,npatch).  The sets S_f come as a schedule the
+ * host derives from the memo replay: frame f either adds sched_idx[sched_ptr[f] ..
+ * sched_ptr[f+1]) to the running set (sched_rebuild[f] == 0) or replaces the set by that
+ * list (sched_rebuild[f] == 1). */
+int mc_xc_ref_mean_except_current(const void* U, const void* V, const int* sched_ptr,
+                                  const int* sched_idx, const uint8_t* sched_rebuild, void* REF,
                                   int t, int npatch, int64_t len, float inv_count, void* stream);
 
 /* ---- a11/a12/a13: per-frame shift post-processing ------------------------------- */

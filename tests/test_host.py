@@ -238,3 +238,18 @@ def test_two_rank_gloo_sharding():
     for _, _, merged, elapsed in results:
         assert merged == {i: [2.0 * i, 2.0 * i] for i in range(5)}
         assert elapsed == pytest.approx(0.2)
+
+
+@pytest.mark.parametrize("t", [5, 40, 51, 60])
+def test_leave_one_out_schedule_replays_the_table(t):
+    """the incremental add/rebuild schedule must reproduce S_f exactly, the way the kernel
+    applies it (rebuild: replace; otherwise: union)"""
+    ref_expo, _, _ = lattice.mask_schedule(t, "mean_except_current", t // 2)
+    ptr, idx, rebuild = lattice.leave_one_out_schedule(ref_expo)
+    running: set = set()
+    for f in range(t):
+        lst = set(idx[ptr[f]:ptr[f + 1]].tolist()) if ptr[f + 1] > ptr[f] else set()
+        running = lst if rebuild[f] else running | lst
+        assert running == {o for o in range(t) if o != f and ref_expo[f, o] == 1}
+    if t <= 50:
+        assert int(rebuild.sum()) == 1  # only frame 0; afterwards one frame joins per step

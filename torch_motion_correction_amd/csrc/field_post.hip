@@ -8,42 +8,37 @@
 
 // ------------------------------------------------------------------ reference spectra
 // REF[f][g][i] = inv * sum_{o != f} (table[f][o] ? V : U)[o][g][i]
-// computed as  T - U_f + sum_{o in S_f} (V_o - U_o)  with S_f updated incrementally
-// while it only grows (the t <= 50 schedule), recomputed when an entry resets (the
-// memo eviction of patch_grid/_patch_grid.py:336-347, t > 50).
-__global__ void ref_mean_except_current(const float* __restrict__ U, const float* __restrict__ V,
-                                        const uint8_t* __restrict__ table, float* __restrict__ REF,
-                                        int t, int64_t n /* floats per frame = npatch*len*2 */,
+//             = inv * ( T - U_f + sum_{o in S_f} (V_o - U_o) ),   T = sum_o U_o,
+// S_f = {o != f : table[f][o]}.  The host turns the t x t table into a schedule: for
+// frame f either "add these o to the running sum" (S_f grew: the t <= 50 case adds one
+// frame per step) or "rebuild from this list" (an entry reset: memo eviction of
+// patch_grid/_patch_grid.py:336-347, t > 50).  sched_ptr[f]..sched_ptr[f+1] indexes
+// sched_idx; sched_rebuild[f] says which.
+__global__ void ref_mean_except_current(const float2* __restrict__ U, const float2* __restrict__ V,
+                                        const int* __restrict__ sched_ptr,
+                                        const int* __restrict__ sched_idx,
+                                        const uint8_t* __restrict__ sched_rebuild,
+                                        float2* __restrict__ REF, int t, int64_t n /* complex */,
                                         float inv) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float T = 0.f;
-  for (int o = 0; o < t; ++o) T += U[(int64_t)o * n + i];
-  float dsum = 0.f;
+  float2 T = make_float2(0.f, 0.f);
+  for (int o = 0; o < t; ++o) {
+    const float2 u = U[(int64_t)o * n + i];
+    T.x += u.x;
+    T.y += u.y;
+  }
+  float2 d = make_float2(0.f, 0.f);
   for (int f = 0; f < t; ++f) {
-    const uint8_t* cur = table + (int64_t)f * t;
-    bool rebuild = (f == 0);
-    if (f > 0) {
-      const uint8_t* prev = table + (int64_t)(f - 1) * t;
-      for (int o = 0; o < t; ++o) {
-        const bool was = (o != f - 1) && prev[o];
-        const bool is = (o != f) && cur[o];
-        if (was && !is) rebuild = true;
-      }
-      if (!rebuild) {
-        for (int o = 0; o < t; ++o) {
-          const bool was = (o != f - 1) && prev[o];
-          const bool is = (o != f) && cur[o];
-          if (is && !was) dsum += V[(int64_t)o * n + i] - U[(int64_t)o * n + i];
-        }
-      }
+    if (sched_rebuild[f]) d = make_float2(0.f, 0.f);
+    for (int q = sched_ptr[f]; q < sched_ptr[f + 1]; ++q) {
+      const int o = sched_idx[q];
+      const float2 v = V[(int64_t)o * n + i], u = U[(int64_t)o * n + i];
+      d.x += v.x - u.x;
+      d.y += v.y - u.y;
     }
-    if (rebuild) {
-      dsum = 0.f;
-      for (int o = 0; o < t; ++o)
-        if (o != f && cur[o]) dsum += V[(int64_t)o * n + i] - U[(int64_t)o * n + i];
-    }
-    REF[(int64_t)f * n + i] = ((T - U[(int64_t)f * n + i]) + dsum) * inv;
+    const float2 uf = U[(int64_t)f * n + i];
+    REF[(int64_t)f * n + i] = make_float2(((T.x - uf.x) + d.x) * inv, ((T.y - uf.y) + d.y) * inv);
   }
 }
 
@@ -195,13 +190,16 @@ __global__ __launch_bounds__(256) void field_smooth_center(const float* __restri
 
 extern "C" {
 
-int mc_xc_ref_mean_except_current(const void* U, const void* V, const uint8_t* table, void* REF,
+int mc_xc_ref_mean_except_current(const void* U, const void* V, const int* sched_ptr,
+                                  const int* sched_idx, const uint8_t* sched_rebuild, void* REF,
                                   int t, int npatch, int64_t len, float inv_count, void* stream) {
-  if (!U || !V || !table || !REF || t < 2 || npatch < 1 || len < 1) return MC_ERR_ARG;
-  const int64_t n = (int64_t)npatch * len * 2;
+  if (!U || !V || !sched_ptr || !sched_idx || !sched_rebuild || !REF || t < 2 || npatch < 1 ||
+      len < 1)
+    return MC_ERR_ARG;
+  const int64_t n = (int64_t)npatch * len;
   hipLaunchKernelGGL(ref_mean_except_current, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, (const float*)U, (const float*)V, table, (float*)REF, t,
-                     n, inv_count);
+                     (hipStream_t)stream, (const float2*)U, (const float2*)V, sched_ptr, sched_idx,
+                     sched_rebuild, (float2*)REF, t, n, inv_count);
   return mc_check_launch();
 }
 

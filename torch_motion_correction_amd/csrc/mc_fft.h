@@ -103,21 +103,39 @@ struct FftPlan {
   }
 };
 
+// Threads that cooperate on one length-N transform in the ping-pong kernels: N/8 (one
+// radix-8 butterfly each), at least one wavefront, at most the workgroup.  A workgroup
+// then runs MC_WG / fft_threads(N) transforms side by side (patch rows: 512 points ->
+// one wavefront per row, four rows at a time).
+__host__ __device__ constexpr int fft_threads(int n) {
+  return (n / 8) < 64 ? 64 : ((n / 8) > MC_WG ? MC_WG : (n / 8));
+}
+
 // Per-thread twiddle bases: the same for every line a thread transforms, so kernels
 // that loop over many lines load them once.  w[pass][it] = exp(-+2 pi i k / (NS*R)).
 template <int N>
 struct FftTwiddles {
   static constexpr int P = FftPlan<N>::npass();
-  cfloat w[P > 1 ? P - 1 : 1][FftPlan<N>::max_iters()];
+  static constexpr int NT = fft_threads(N);
+  static constexpr int max_iters() {
+    int m = 1;
+    for (int p = 0; p < P; ++p) {
+      const int it = (N / FftPlan<N>::radix(p) + NT - 1) / NT;
+      m = it > m ? it : m;
+    }
+    return m;
+  }
+  cfloat w[P > 1 ? P - 1 : 1][max_iters()];
+  // lt = thread index within the transform's sub-group, 0 <= lt < NT
   template <int DIR>
-  __device__ __forceinline__ void init(int tid, const cfloat* __restrict__ tw, int tw_stride) {
+  __device__ __forceinline__ void init(int lt, const cfloat* __restrict__ tw, int tw_stride) {
 #pragma unroll
     for (int p = 1; p < P; ++p) {
       const int R = FftPlan<N>::radix(p), NS = FftPlan<N>::ns(p), NB = N / R;
-      const int IT = (NB + MC_WG - 1) / MC_WG;
+      const int IT = (NB + NT - 1) / NT;
 #pragma unroll
       for (int it = 0; it < IT; ++it) {
-        const int j = tid + it * MC_WG;
+        const int j = lt + it * NT;
         const int k = j & (NS - 1);
         cfloat v = tw[(j < NB ? k : 0) * (N / (NS * R)) * tw_stride];
         if (DIR > 0) v.y = -v.y;
@@ -127,18 +145,19 @@ struct FftTwiddles {
   }
 };
 
-// One Stockham pass (index PASS of the plan).  LOAD/STORE functors as in wg_fft.
+// One Stockham pass (index PASS of the plan) by the NT threads of a sub-group.
 template <int N, int PASS, int DIR, typename Load, typename Store>
-__device__ __forceinline__ void fft_pass2(int tid, const FftTwiddles<N>& T, Load load, Store store) {
+__device__ __forceinline__ void fft_pass2(int lt, const FftTwiddles<N>& T, Load load, Store store) {
   constexpr int R = FftPlan<N>::radix(PASS);
   constexpr int NS = FftPlan<N>::ns(PASS);
   constexpr int NB = N / R;
-  constexpr int IT = (NB + MC_WG - 1) / MC_WG;
+  constexpr int NT = fft_threads(N);
+  constexpr int IT = (NB + NT - 1) / NT;
   cfloat v[IT][R];
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
-    const int j = tid + it * MC_WG;
-    if (NB >= MC_WG || j < NB) {
+    const int j = lt + it * NT;
+    if (NB % NT == 0 || j < NB) {
 #pragma unroll
       for (int m = 0; m < R; ++m) v[it][m] = load(j + m * NB, it, m);
       if constexpr (NS > 1) {
@@ -166,15 +185,16 @@ __device__ __forceinline__ void fft_pass2(int tid, const FftTwiddles<N>& T, Load
   }
 }
 
-// Ping-pong transform over two LDS lines: pass p reads line[(s+p-1)&1] (p>0) and writes
-// line[(s+p)&1]; one barrier after every LDS-writing pass, none between a pass's reads
-// and writes.  The first pass reads through `load(i, it, m)` (it, m = position of
-// element i in this thread's first-pass registers, for register-prefetched inputs);
-// the last pass writes through `store(i, v)` when LAST_TO_FUNCTOR, else to LDS.
-// Returns the index of the line holding the result (when written to LDS).
-// Buffer discipline for loops: start the next line at (result_line ^ 1) -- see xc_fft.hip.
+// Ping-pong transform over two LDS lines (l0, l1: this sub-group's own pair): pass p reads
+// line (s+p-1)&1 (p>0) and writes line (s+p)&1; one workgroup barrier after every
+// LDS-writing pass, none between a pass's reads and writes.  Every sub-group of the
+// workgroup must run the same sequence (the barriers are workgroup-wide).  The first pass
+// reads through `load(i, it, m)` (it, m = position of element i in this thread's
+// first-pass registers); the last pass writes through `store(i, v)` when
+// LAST_TO_FUNCTOR, else to LDS.  Returns the index of the line that was read or written
+// last; the next transform of a loop must start at (that ^ 1) -- see xc_fft.hip.
 template <int N, int DIR, bool LAST_TO_FUNCTOR, int PASS, typename Load, typename Store>
-__device__ __forceinline__ int fft_pp_rec(cfloat* l0, cfloat* l1, int s, int tid,
+__device__ __forceinline__ int fft_pp_rec(cfloat* l0, cfloat* l1, int s, int lt,
                                           const FftTwiddles<N>& T, Load load, Store store) {
   constexpr int P = FftPlan<N>::npass();
   cfloat* src = ((s + PASS + 1) & 1) ? l1 : l0;
@@ -183,33 +203,33 @@ __device__ __forceinline__ int fft_pp_rec(cfloat* l0, cfloat* l1, int s, int tid
   auto lds_store = [dst](int i, cfloat v) { dst[lpad(i)] = v; };
   constexpr bool LAST = (PASS == P - 1);
   if constexpr (PASS == 0 && LAST) {
-    if constexpr (LAST_TO_FUNCTOR) fft_pass2<N, PASS, DIR>(tid, T, load, store);
-    else { fft_pass2<N, PASS, DIR>(tid, T, load, lds_store); __syncthreads(); }
+    if constexpr (LAST_TO_FUNCTOR) fft_pass2<N, PASS, DIR>(lt, T, load, store);
+    else { fft_pass2<N, PASS, DIR>(lt, T, load, lds_store); __syncthreads(); }
     return (s + PASS) & 1;
   } else if constexpr (PASS == 0) {
-    fft_pass2<N, PASS, DIR>(tid, T, load, lds_store);
+    fft_pass2<N, PASS, DIR>(lt, T, load, lds_store);
     __syncthreads();
-    return fft_pp_rec<N, DIR, LAST_TO_FUNCTOR, PASS + 1>(l0, l1, s, tid, T, load, store);
+    return fft_pp_rec<N, DIR, LAST_TO_FUNCTOR, PASS + 1>(l0, l1, s, lt, T, load, store);
   } else if constexpr (LAST) {
     if constexpr (LAST_TO_FUNCTOR) {
-      fft_pass2<N, PASS, DIR>(tid, T, lds_load, store);
+      fft_pass2<N, PASS, DIR>(lt, T, lds_load, store);
       return (s + PASS + 1) & 1;
     } else {
-      fft_pass2<N, PASS, DIR>(tid, T, lds_load, lds_store);
+      fft_pass2<N, PASS, DIR>(lt, T, lds_load, lds_store);
       __syncthreads();
       return (s + PASS) & 1;
     }
   } else {
-    fft_pass2<N, PASS, DIR>(tid, T, lds_load, lds_store);
+    fft_pass2<N, PASS, DIR>(lt, T, lds_load, lds_store);
     __syncthreads();
-    return fft_pp_rec<N, DIR, LAST_TO_FUNCTOR, PASS + 1>(l0, l1, s, tid, T, load, store);
+    return fft_pp_rec<N, DIR, LAST_TO_FUNCTOR, PASS + 1>(l0, l1, s, lt, T, load, store);
   }
 }
 
 template <int N, int DIR, bool LAST_TO_FUNCTOR, typename Load, typename Store>
-__device__ __forceinline__ int wg_fft_pp(cfloat* l0, cfloat* l1, int s, int tid,
+__device__ __forceinline__ int wg_fft_pp(cfloat* l0, cfloat* l1, int s, int lt,
                                          const FftTwiddles<N>& T, Load load, Store store) {
-  return fft_pp_rec<N, DIR, LAST_TO_FUNCTOR, 0>(l0, l1, s, tid, T, load, store);
+  return fft_pp_rec<N, DIR, LAST_TO_FUNCTOR, 0>(l0, l1, s, lt, T, load, store);
 }
 
 // One Stockham pass of radix R at sub-transform length NS (product of earlier

@@ -38,19 +38,25 @@ struct XcBox {  // central box of normalize_image (utils.py:76-81) in window coo
   int hl, hu, wl, wu;
 };
 
-template <int LOGN, int PREFETCH, bool STATS>
+// Sub-groups: fft_threads(N) threads cooperate on one row, MC_WG / that many rows are in
+// flight per workgroup (N = 2048: the whole workgroup on one row; N = 512: one wavefront
+// per row, four rows at a time).  Each sub-group owns a pair of LDS lines (ping-pong: one
+// barrier per pass); twiddles live in registers for the whole row loop.
+template <int LOGN, bool STATS>
 __global__ __launch_bounds__(MC_WG) void xc_rows_fwd(
     const float* __restrict__ src, const int64_t* __restrict__ job_off, int64_t row_stride,
     const int* __restrict__ job_expo, const float* __restrict__ mask,
     const float* __restrict__ mean_rstd, cfloat* __restrict__ T1,
     const cfloat* __restrict__ tw_row, XcGeom g, XcBox box, double* __restrict__ stats_acc) {
   constexpr int N = 1 << LOGN;  // complex length = W/2
-  constexpr int R0 = FftPlan<N>::radix(0), NB0 = N / R0, IT0 = FftPlan<N>::iters(0);
+  constexpr int NT = fft_threads(N), SG = MC_WG / NT;
+  constexpr int R0 = FftPlan<N>::radix(0), NB0 = N / R0, IT0 = (NB0 + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  cfloat* l0 = reinterpret_cast<cfloat*>(smem);
-  cfloat* l1 = l0 + lds_len(N);
-  cfloat* stg = l1 + lds_len(N);
   const int tid = threadIdx.x;
+  const int lt = tid & (NT - 1), sg = tid / NT;
+  cfloat* l0 = reinterpret_cast<cfloat*>(smem) + sg * 2 * lds_len(N);
+  cfloat* l1 = l0 + lds_len(N);
+  cfloat* stg = reinterpret_cast<cfloat*>(smem) + SG * 2 * lds_len(N);
   // job is the fastest grid dimension: the workgroups that share a row group's mask rows
   // (one per job) are dispatched together and find them in L2
   const int job = blockIdx.x;
@@ -61,39 +67,36 @@ __global__ __launch_bounds__(MC_WG) void xc_rows_fwd(
   const int expo = job_expo ? job_expo[job] : (mask ? 1 : 0);
   const float* base = src + job_off[job];
   FftTwiddles<N> T;
-  T.template init<-1>(tid, tw_row, 2);
+  T.template init<-1>(lt, tw_row, 2);
 
-  cfloat pxA[IT0][R0], mkA[IT0][R0], pxB[IT0][R0], mkB[IT0][R0];
-  auto issue = [&](int r, cfloat (&p)[IT0][R0], cfloat (&m)[IT0][R0]) {
+  int s = 0;
+  float st_s = 0.f, st_q = 0.f;  // sum and sum of squares of (x - mean_rstd[0]) inside the box
+  for (int r = sg; r < RG; r += SG) {  // RG % SG == 0: every sub-group runs the same trip count
     const int y = g.y0 + grp * RG + r;
     const float* row = base + (int64_t)y * row_stride;
     const float* mrow = mask + (int64_t)y * g.W;
+    cfloat px[IT0][R0], mk[IT0][R0];
 #pragma unroll
     for (int it = 0; it < IT0; ++it) {
-      const int j = tid + it * MC_WG;
+      const int j = lt + it * NT;
 #pragma unroll
       for (int q = 0; q < R0; ++q) {
         const int x = 2 * (j + q * NB0);
-        const bool on = (NB0 >= MC_WG || j < NB0) && x >= g.x0 && x < g.x1;
-        p[it][q] = on ? cmake(row[x], row[x + 1]) : cmake(mean, mean);
-        m[it][q] = (on && expo > 0) ? cmake(mrow[x], mrow[x + 1]) : cmake(on ? 1.f : 0.f, on ? 1.f : 0.f);
+        const bool on = (NB0 % NT == 0 || j < NB0) && x >= g.x0 && x < g.x1;
+        px[it][q] = on ? cmake(row[x], row[x + 1]) : cmake(mean, mean);
+        mk[it][q] = (on && expo > 0) ? cmake(mrow[x], mrow[x + 1]) : cmake(on ? 1.f : 0.f, on ? 1.f : 0.f);
       }
     }
-  };
-  int s = 0;
-  float st_s = 0.f, st_q = 0.f;  // sum and sum of squares of (x - mean_rstd[0]) inside the box
-  auto process = [&](int r, cfloat (&p)[IT0][R0], cfloat (&m)[IT0][R0]) {
     if constexpr (STATS) {
-      const int y = g.y0 + grp * RG + r;
       if (y >= box.hl && y < box.hu) {
 #pragma unroll
         for (int it = 0; it < IT0; ++it)
 #pragma unroll
           for (int q = 0; q < R0; ++q) {
-            const int x = 2 * (tid + it * MC_WG + q * NB0);
-            if ((NB0 >= MC_WG || tid + it * MC_WG < NB0) && x >= box.wl && x < box.wu) {
-              // box.wl/wu are even here (host guarantees), so x+1 is inside too
-              const float a = p[it][q].x - mean, b = p[it][q].y - mean;
+            const int x = 2 * (lt + it * NT + q * NB0);
+            if ((NB0 % NT == 0 || lt + it * NT < NB0) && x >= box.wl && x < box.wu) {
+              // box.wl/wu are even (host guarantees), so x+1 is inside too
+              const float a = px[it][q].x - mean, b = px[it][q].y - mean;
               st_s += a + b;
               st_q += a * a + b * b;
             }
@@ -101,8 +104,8 @@ __global__ __launch_bounds__(MC_WG) void xc_rows_fwd(
       }
     }
     auto load = [&](int, int it, int q) {
-      cfloat v = cmake((p[it][q].x - mean) * rstd, (p[it][q].y - mean) * rstd);
-      const cfloat mm = m[it][q];
+      cfloat v = cmake((px[it][q].x - mean) * rstd, (px[it][q].y - mean) * rstd);
+      const cfloat mm = mk[it][q];
       v.x *= mm.x;
       v.y *= mm.y;
       for (int e = 1; e < expo; ++e) {
@@ -112,10 +115,10 @@ __global__ __launch_bounds__(MC_WG) void xc_rows_fwd(
       return v;
     };
     auto nostore = [](int, cfloat) {};
-    const int res = wg_fft_pp<N, -1, false>(l0, l1, s, tid, T, load, nostore);
+    const int res = wg_fft_pp<N, -1, false>(l0, l1, s, lt, T, load, nostore);
     const cfloat* Z = res ? l1 : l0;
     // real-FFT unpack: X[k] = (Z[k] + conj(Z[N-k]))/2 - i/2 * w^k * (Z[k] - conj(Z[N-k]))
-    for (int k = tid; k < g.nkx; k += MC_WG) {
+    for (int k = lt; k < g.nkx; k += NT) {
       const cfloat zk = Z[lpad(k & (N - 1))];
       const cfloat zm = cconj(Z[lpad((N - k) & (N - 1))]);
       const cfloat sm = cadd(zk, zm), d = csub(zk, zm);
@@ -124,22 +127,6 @@ __global__ __launch_bounds__(MC_WG) void xc_rows_fwd(
       stg[k * (RG + 1) + r] = cmake(0.5f * (sm.x + wd.y), 0.5f * (sm.y - wd.x));
     }
     s = res ^ 1;  // next row must not start in the line that is still being unpacked
-  };
-  if constexpr (PREFETCH) {
-    issue(0, pxA, mkA);
-    for (int r = 0; r < RG; r += 2) {
-      if (r + 1 < RG) issue(r + 1, pxB, mkB);
-      process(r, pxA, mkA);
-      if (r + 1 < RG) {
-        if (r + 2 < RG) issue(r + 2, pxA, mkA);
-        process(r + 1, pxB, mkB);
-      }
-    }
-  } else {
-    for (int r = 0; r < RG; ++r) {
-      issue(r, pxA, mkA);
-      process(r, pxA, mkA);
-    }
   }
   __syncthreads();
   cfloat* out = T1 + (int64_t)job * g.nkx * g.ny + (int64_t)grp * RG;
@@ -310,12 +297,14 @@ __global__ __launch_bounds__(MC_WG) void xc_rows_inv(const cfloat* __restrict__ 
                                                      const cfloat* __restrict__ tw_row, XcGeom g,
                                                      int near, int phase) {
   constexpr int N = 1 << LOGN;
-  constexpr int R0 = FftPlan<N>::radix(0), NB0 = N / R0, IT0 = FftPlan<N>::iters(0);
+  constexpr int NT = fft_threads(N), SG = MC_WG / NT;
+  constexpr int R0 = FftPlan<N>::radix(0), NB0 = N / R0, IT0 = (NB0 + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  cfloat* l0 = reinterpret_cast<cfloat*>(smem);
-  cfloat* l1 = l0 + lds_len(N);
-  cfloat* stg = l1 + lds_len(N);
   const int tid = threadIdx.x;
+  const int lt = tid & (NT - 1), sg = tid / NT;
+  cfloat* l0 = reinterpret_cast<cfloat*>(smem) + sg * 2 * lds_len(N);
+  cfloat* l1 = l0 + lds_len(N);
+  cfloat* stg = reinterpret_cast<cfloat*>(smem) + SG * 2 * lds_len(N);
   const int p = blockIdx.y;
   const int RG = g.RG;
   const int ngrp = g.H / RG;
@@ -359,15 +348,15 @@ __global__ __launch_bounds__(MC_WG) void xc_rows_inv(const cfloat* __restrict__ 
     if (skip) return;
   }
   FftTwiddles<N> T;
-  T.template init<+1>(tid, tw_row, 2);
+  T.template init<+1>(lt, tw_row, 2);
   // c2r pack twiddles conj(w^k) for this thread's first-pass elements
   cfloat wk[IT0][R0];
 #pragma unroll
   for (int it = 0; it < IT0; ++it)
 #pragma unroll
     for (int q = 0; q < R0; ++q) {
-      const int j = tid + it * MC_WG;
-      const int k = (NB0 >= MC_WG || j < NB0) ? j + q * NB0 : 0;
+      const int j = lt + it * NT;
+      const int k = (NB0 % NT == 0 || j < NB0) ? j + q * NB0 : 0;
       cfloat w = tw_row[k];
       w.y = -w.y;
       wk[it][q] = w;
@@ -376,7 +365,7 @@ __global__ __launch_bounds__(MC_WG) void xc_rows_inv(const cfloat* __restrict__ 
   float bv = -INFINITY;
   int bi = 0x7fffffff;
   int s = 0;
-  for (int r = 0; r < RG; ++r) {
+  for (int r = sg; r < RG; r += SG) {  // RG % SG == 0
     const int y = grp * RG + r;
     // c2r pack: Z[k] = (X[k] + conj(X[N-k])) + i * conj(w^k) * (X[k] - conj(X[N-k]))
     auto load = [&](int k, int it, int q) {
@@ -398,14 +387,14 @@ __global__ __launch_bounds__(MC_WG) void xc_rows_inv(const cfloat* __restrict__ 
         cand_merge(bv, bi, v.x, flat);
         cand_merge(bv, bi, v.y, flat + 1);
       };
-      res = wg_fft_pp<N, +1, true>(l0, l1, s, tid, T, load, store);
+      res = wg_fft_pp<N, +1, true>(l0, l1, s, lt, T, load, store);
     } else {
       float* orow = out_real + out_off[p] + (int64_t)y * out_stride;
       auto store = [&](int n, cfloat v) {
         orow[2 * n] = v.x;
         orow[2 * n + 1] = v.y;
       };
-      res = wg_fft_pp<N, +1, true>(l0, l1, s, tid, T, load, store);
+      res = wg_fft_pp<N, +1, true>(l0, l1, s, lt, T, load, store);
     }
     s = res ^ 1;  // the last pass still reads line[res] while the next row starts
   }
@@ -536,6 +525,7 @@ static int geom_from(const mc_xc_geom* q, XcGeom* g) {
   if (q->nkx < 1 || q->nkx > q->W / 2 + 1) return MC_ERR_ARG;
   if (q->kyp < 0 || q->kyn < 0 || q->kyp + q->kyn < 1 || q->kyp + q->kyn > q->H) return MC_ERR_ARG;
   if (q->RG < 1 || q->ny < 1 || q->ny % q->RG || q->H % q->RG) return MC_ERR_ARG;
+  if (q->RG % (MC_WG / fft_threads(q->W / 2))) return MC_ERR_ARG;  // rows per group vs sub-groups
   if (q->y0 < 0 || q->y0 + q->ny > q->H) return MC_ERR_ARG;
   if (q->x0 < 0 || q->x1 > q->W || (q->x0 & 1) || (q->x1 & 1) || q->x0 >= q->x1) return MC_ERR_ARG;
   g->W = q->W; g->H = q->H; g->nkx = q->nkx; g->kyp = q->kyp; g->kyn = q->kyn;
@@ -544,7 +534,8 @@ static int geom_from(const mc_xc_geom* q, XcGeom* g) {
 }
 
 static size_t rows_lds_bytes(int N, const XcGeom& g) {
-  return sizeof(cfloat) * (2 * (size_t)lds_len(N) + (size_t)g.nkx * (g.RG + 1));
+  const int sgroups = MC_WG / fft_threads(N);
+  return sizeof(cfloat) * ((size_t)sgroups * 2 * lds_len(N) + (size_t)g.nkx * (g.RG + 1));
 }
 
 extern "C" {
@@ -568,14 +559,9 @@ static int rows_forward_impl(const float* src, const int64_t* job_off, int64_t r
   const size_t lds = rows_lds_bytes(g.W / 2, g);
   if (lds > 160 * 1024) return MC_ERR_ARG;
   dim3 grid(njobs, g.ny / g.RG);
-  static int variant = -1;
-  if (variant < 0) {
-    const char* v = getenv("MC_K1_VARIANT");
-    variant = v ? atoi(v) : 0;
-  }
   XcBox b = box ? *box : XcBox{0, 0, 0, 0};
   MC_DISPATCH_LOG(logn, {
-    auto k = stats_acc ? xc_rows_fwd<L, 0, true> : (variant == 1 ? xc_rows_fwd<L, 1, false> : xc_rows_fwd<L, 0, false>);
+    auto k = stats_acc ? xc_rows_fwd<L, true> : xc_rows_fwd<L, false>;
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, grid, dim3(MC_WG), lds, (hipStream_t)stream, src, job_off, row_stride,

@@ -227,10 +227,11 @@ def patch_field(img, stats, pixel_spacing, reference_frame, reference_strategy, 
             off, ex1 = jobs(range(t), [1] * t)
             U = _forward_spectra(img, off, w, ex1, pl, stats)
             V = _forward_spectra(img, off, w, ex1 * 2, pl, stats)
-            table = torch.as_tensor((ref_expo == 1).astype(np.uint8), device=dev).contiguous()
+            sp, si, sr = lattice.leave_one_out_schedule(ref_expo)
+            sp, si, sr = _i32(sp, dev), _i32(si, dev), torch.as_tensor(sr, device=dev)
             REF = torch.empty_like(U)
-            check(lib.mc_xc_ref_mean_except_current(ptr(U), ptr(V), ptr(table), ptr(REF), t, npatch,
-                                                    g.nkx * g.nky, 1.0 / (t - 1), st),
+            check(lib.mc_xc_ref_mean_except_current(ptr(U), ptr(V), ptr(sp), ptr(si), ptr(sr), ptr(REF),
+                                                    t, npatch, g.nkx * g.nky, 1.0 / (t - 1), st),
                   "mc_xc_ref_mean_except_current")
             del V
             S_cur, S_ref = U, REF

@@ -110,3 +110,27 @@ def mask_schedule(t: int, reference_strategy: str, reference_frame: int):
         cbox[0] += 1  # frame_patches *= mask on the memo's own tensor
         processed.append(f)
     return ref_expo, cur_expo, processed
+
+
+def leave_one_out_schedule(ref_expo: np.ndarray):
+    """Turn the (t,t) exponent table of `mask_schedule` (mean_except_current) into the
+    incremental schedule libmcorr's reference-spectrum kernel consumes: S_f = {o != f :
+    ref_expo[f,o] == 1}; frame f lists the members to ADD to S_{f-1} when S_f is a
+    superset of it, else (an entry was reset by the memo eviction) all of S_f with
+    rebuild=1.  Returns (ptr[t+1], idx[...], rebuild[t]) as int32/int32/uint8 arrays."""
+    t = ref_expo.shape[0]
+    ptr, idx, rebuild = [0], [], []
+    prev: set[int] = set()
+    for f in range(t):
+        cur = {o for o in range(t) if o != f and ref_expo[f, o] == 1}
+        if f > 0 and f not in prev and prev <= cur:
+            add = sorted(cur - prev)
+            rebuild.append(0)
+        else:
+            add = sorted(cur)
+            rebuild.append(1)
+        idx.extend(add)
+        ptr.append(len(idx))
+        prev = cur
+    return (np.asarray(ptr, dtype=np.int32), np.asarray(idx if idx else [0], dtype=np.int32),
+            np.asarray(rebuild, dtype=np.uint8))

@@ -65,8 +65,10 @@ def xc_geometry(h: int, w: int, high: float, radius: float, smoothing: float) ->
     x0 -= x0 & 1
     x1 += x1 & 1
     n_line = w // 2
+    subgroups = 256 // min(256, max(64, n_line // 8))  # rows transformed side by side (mc_fft.h)
+    lines = subgroups * 2 * (n_line + (n_line >> 4) + 1)
     rg = 16
-    while rg > 1 and 8 * (2 * (n_line + (n_line >> 4) + 1) + nkx * (rg + 1)) > LDS_BUDGET:
+    while rg > subgroups and 8 * (lines + nkx * (rg + 1)) > LDS_BUDGET:
         rg //= 2
     rg = min(rg, h)
     y0 -= y0 % rg
