@@ -777,6 +777,344 @@ void warp_rigid_dma(RigidArgs a) {
 }
 #pragma clang fp contract(off)
 
+// ------------------------------------------------------------------ general warp, LDS tile
+// Per (tile, frame): the shift at the tile centre positions a (32+3+2*MG) x (256+3+2*MG)
+// input window that is DMA'd into LDS; every pixel then runs the reference's per-pixel
+// coordinate chain (strict fp32, see file header) and gathers its 4x4 taps from LDS.
+// Lane l owns pixels x = x_tile + l + 64k (k = 0..3): adjacent lanes read adjacent LDS
+// words, so the data-dependent gathers are bank-conflict free.
+//
+// Whether ALL taps of a tile fit the window is decided up front, rigorously: a pixel's
+// shift is a bicubic (A = -0.75) interpolation of lattice nodes, sum(w) = 1 and
+// sum|w| <= 1.375^2 < 1.9 in 2-D, so with rho = half the range of the nodes that can
+// influence the tile every shift lies within 1.9*rho of the mid-range value and within
+// 3.8*rho of the centre pixel's.  Tile-frames that fail the test are only flagged here and
+// are processed afterwards by warp_field_slow (generic global gathers).
+// The x-direction of the shift-lattice upsample comes from the E table (warp_etab); a
+// thread caches its 4 px x 4 lattice rows x 2 channels of E in registers while
+// consecutive pixel rows use the same lattice rows (they almost always do).
+#define GW_MG 6
+#define GW_ROWS (RIGID_WAVES * RIGID_ROWS + 3 + 2 * GW_MG)              // 47
+#define GW_QUADS ((RIGID_LANES * 4 + 3 + 2 * GW_MG + 3 + 3) / 4)         // 70 (alignment slack)
+#define GW_STRIDE (4 * GW_QUADS)                                          // 280 floats
+#define GW_NQ (GW_ROWS * GW_QUADS)
+#define GW_QUADS_PAD (((GW_NQ + 63) / 64) * 64)
+
+#pragma clang fp contract(fast)
+__device__ __forceinline__ float gw_dot4(const float w[4], float a, float b, float c, float d) {
+  return ((w[0] * a + w[1] * b) + w[2] * c) + w[3] * d;
+}
+#pragma clang fp contract(off)
+
+struct FieldArgs {
+  WarpArgs w;
+  const float* lattice;  // [f][2][GH][GW]
+  const int* xtap;       // [w][4]
+  int GW;
+  unsigned char* flags;  // [f][tile]: 1 = irregular, left to warp_field_slow
+};
+
+__device__ __forceinline__ int wave_min_i(int v) {
+  for (int off = 32; off > 0; off >>= 1) {
+    const int o = __shfl_xor(v, off);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+  for (int off = 32; off > 0; off >>= 1) {
+    const int o = __shfl_xor(v, off);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+__device__ __forceinline__ float wave_min_f(float v) {
+  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+  return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+  return v;
+}
+
+template <bool WRITE_FRAMES, bool WRITE_SUM, bool UNIT_PS>
+__global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES, 2) void warp_field(FieldArgs fa) {
+  const WarpArgs& a = fa.w;
+  extern __shared__ __attribute__((aligned(16))) char smem_gw[];
+  float4* const tile4 = reinterpret_cast<float4*>(smem_gw);
+  float* const tile = reinterpret_cast<float*>(smem_gw);
+  __shared__ int s_ytap[RIGID_WAVES * RIGID_ROWS][4];
+  __shared__ float s_ycoef[RIGID_WAVES * RIGID_ROWS][4];
+  const int nt = a.tiles_x * a.tiles_y;
+  const int b = blockIdx.x;
+  int tl = b;
+  if ((nt & 7) == 0) tl = (b & 7) * (nt >> 3) + (b >> 3);
+  const int tyi = tl / a.tiles_x, txi = tl - tyi * a.tiles_x;
+  const int h = a.h, w = a.w;
+  const float fh = (float)h, fw = (float)w;
+  const int lane = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int tid = wave * RIGID_LANES + lane;
+  const int xt = txi * (RIGID_LANES * 4);
+  const int yt = tyi * (RIGID_WAVES * RIGID_ROWS);
+  const int y0 = yt + wave * RIGID_ROWS;
+  const int64_t hw = (int64_t)h * w;
+  // frame-invariant per-row lattice taps of this tile
+  if (tid < RIGID_WAVES * RIGID_ROWS) {
+    const int y = yt + tid < h ? yt + tid : h - 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      s_ytap[tid][k] = a.ytap[4 * y + k];
+      s_ycoef[tid][k] = a.ycoef[4 * y + k];
+    }
+  }
+  // lattice footprint of the tile (frame-invariant): node rows [R0,R1], node columns [C0,C1]
+  int R0, R1, C0, C1;
+  {
+    int lo = 0x7fffffff, hi = -1;
+    if (lane < RIGID_WAVES * RIGID_ROWS) {
+      const int y = yt + lane < h ? yt + lane : h - 1;
+      for (int k = 0; k < 4; ++k) {
+        const int v = a.ytap[4 * y + k];
+        lo = v < lo ? v : lo;
+        hi = v > hi ? v : hi;
+      }
+    }
+    R0 = wave_min_i(lo);
+    R1 = wave_max_i(hi);
+    lo = 0x7fffffff;
+    hi = -1;
+    for (int k = 0; k < 4; ++k) {
+      const int x = xt + lane + 64 * k;
+      const int xs = x < w ? x : w - 1;
+      for (int j = 0; j < 4; ++j) {
+        const int v = fa.xtap[4 * xs + j];
+        lo = v < lo ? v : lo;
+        hi = v > hi ? v : hi;
+      }
+    }
+    C0 = wave_min_i(lo);
+    C1 = wave_max_i(hi);
+  }
+  // centre pixel of the tile (clipped to the image)
+  const int yc = (yt + 16 < h) ? yt + 16 : h - 1;
+  const int xc = (xt + 128 < w) ? xt + 128 : w - 1;
+  const int4 ytc = *reinterpret_cast<const int4*>(a.ytap + 4 * yc);
+  const float4 ycc = *reinterpret_cast<const float4*>(a.ycoef + 4 * yc);
+  float acc[RIGID_ROWS][4];
+#pragma unroll
+  for (int r = 0; r < RIGID_ROWS; ++r)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[r][k] = 0.f;
+  __syncthreads();
+
+  for (int f = 0; f < a.nframes; ++f) {
+    const float* fr = a.frames + (int64_t)f * hw;
+    const float* E = a.etab + (int64_t)f * 2 * a.GH * w;
+    const int64_t chs = (int64_t)a.GH * w;  // channel stride of E
+    // 0. regularity: range of the lattice nodes that can influence this tile
+    {
+      const float* L = fa.lattice + (int64_t)f * 2 * a.GH * fa.GW;
+      const int ncol = C1 - C0 + 1, nnode = (R1 - R0 + 1) * ncol;
+      float lo_y = 3.0e38f, hi_y = -3.0e38f, lo_x = 3.0e38f, hi_x = -3.0e38f;
+      for (int i = lane; i < nnode; i += RIGID_LANES) {
+        const int R = R0 + i / ncol, Cc = C0 + i % ncol;
+        const float vy = L[(int64_t)R * fa.GW + Cc], vx = L[(int64_t)(a.GH + R) * fa.GW + Cc];
+        lo_y = fminf(lo_y, vy); hi_y = fmaxf(hi_y, vy);
+        lo_x = fminf(lo_x, vx); hi_x = fmaxf(hi_x, vx);
+      }
+      const float ry = 0.5f * (wave_max_f(hi_y) - wave_min_f(lo_y)) / a.pixel_spacing;
+      const float rx = 0.5f * (wave_max_f(hi_x) - wave_min_f(lo_x)) / a.pixel_spacing;
+      // |shift - shift_centre| <= 3.8*rho; taps span [-1,+2] around floor(); coordinate
+      // rounding adds < 0.01 px.  NaNs fail the comparison and go to the slow kernel.
+      const bool regular = (3.8f * ry + 1.05f <= (float)GW_MG) && (3.8f * rx + 1.05f <= (float)GW_MG);
+      if (!regular) {  // workgroup-uniform: every wave computed the same numbers
+        if (tid == 0) fa.flags[(int64_t)f * nt + tl] = 1;
+        continue;
+      }
+    }
+    // 1. window origin from the shift at the tile centre (identical in every lane)
+    int wy0, ax;
+    {
+      const float* Ec = E + xc;
+      float sy = dot4(ycc, Ec[(int64_t)ytc.x * w], Ec[(int64_t)ytc.y * w], Ec[(int64_t)ytc.z * w],
+                      Ec[(int64_t)ytc.w * w]);
+      float sx = dot4(ycc, Ec[chs + (int64_t)ytc.x * w], Ec[chs + (int64_t)ytc.y * w],
+                      Ec[chs + (int64_t)ytc.z * w], Ec[chs + (int64_t)ytc.w * w]);
+      if (!UNIT_PS) {
+        sy = sy / a.pixel_spacing;
+        sx = sx / a.pixel_spacing;
+      }
+      const float lim = 4.f * (fh + fw);
+      const float dy = fminf(fmaxf(floorf(grid_chain((float)yc + sy, fh)) - (float)yc, -lim), lim);
+      const float dx = fminf(fmaxf(floorf(grid_chain((float)xc + sx, fw)) - (float)xc, -lim), lim);
+      wy0 = __builtin_amdgcn_readfirstlane(yt + (int)dy - 1 - GW_MG);
+      ax = __builtin_amdgcn_readfirstlane((xt + (int)dx - 1 - GW_MG) & ~3);
+    }
+    // 2. window -> LDS (the previous frame's reads are behind the barrier at the loop's end)
+    for (int i = wave; i < GW_QUADS_PAD / 64; i += RIGID_WAVES) {
+      int q = i * 64 + lane;
+      q = q < GW_NQ ? q : GW_NQ - 1;
+      const int tr = q / GW_QUADS, qc = q - tr * GW_QUADS;
+      int r = wy0 + tr;
+      r = r < 0 ? 0 : (r > h - 1 ? h - 1 : r);
+      int c = ax + 4 * qc;
+      c = c < 0 ? 0 : (c > w - 4 ? w - 4 : c);
+      __builtin_amdgcn_global_load_lds(fr + (int64_t)r * w + c, (lds_vptr)(tile4 + i * 64), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (ax < 0 || ax + GW_STRIDE > w) {  // border padding: clipped columns (edge tiles only)
+      for (int i = tid; i < GW_ROWS * GW_STRIDE; i += RIGID_LANES * RIGID_WAVES) {
+        const int tr = i / GW_STRIDE, e = i - tr * GW_STRIDE;
+        const int c = ax + e;
+        if (c < 0 || c > w - 1) {
+          const int cc = c < 0 ? 0 : w - 1;
+          int qsrc = (cc & ~3) - ax;
+          qsrc = qsrc < 0 ? 0 : (qsrc > GW_STRIDE - 4 ? GW_STRIDE - 4 : qsrc);
+          tile[tr * GW_STRIDE + e] = tile[tr * GW_STRIDE + qsrc + (cc & 3)];
+        }
+      }
+      __syncthreads();
+    }
+    // 3. pixels
+    int4 ycache = make_int4(-1, -1, -1, -1);
+    float ey[4][4], ex[4][4];  // [lattice tap][pixel k]
+#pragma unroll
+    for (int r = 0; r < RIGID_ROWS; ++r) {
+      const int y = y0 + r;
+      if (y >= h) break;
+      const int row = wave * RIGID_ROWS + r;
+      const int4 yt4 = make_int4(s_ytap[row][0], s_ytap[row][1], s_ytap[row][2], s_ytap[row][3]);
+      const float4 yc4 = make_float4(s_ycoef[row][0], s_ycoef[row][1], s_ycoef[row][2], s_ycoef[row][3]);
+      if (yt4.x != ycache.x || yt4.y != ycache.y || yt4.z != ycache.z || yt4.w != ycache.w) {
+        ycache = yt4;  // wave-uniform: depends on y only
+        const int rows4[4] = {yt4.x, yt4.y, yt4.z, yt4.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int x = xt + lane + 64 * k;
+            const int xs = x < w ? x : w - 1;
+            ey[i][k] = E[(int64_t)rows4[i] * w + xs];
+            ex[i][k] = E[chs + (int64_t)rows4[i] * w + xs];
+          }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        // one pixel at a time: without this the scheduler interleaves all 32 unrolled
+        // pixel bodies and the kernel spills
+        __builtin_amdgcn_sched_barrier(0);
+        const int x = xt + lane + 64 * k;
+        if (x >= w) continue;
+        float sy = dot4(yc4, ey[0][k], ey[1][k], ey[2][k], ey[3][k]);
+        float sx = dot4(yc4, ex[0][k], ex[1][k], ex[2][k], ex[3][k]);
+        if (!UNIT_PS) {
+          sy = sy / a.pixel_spacing;
+          sx = sx / a.pixel_spacing;
+        }
+        const float cy = (float)y + sy, cx = (float)x + sx;
+        const bool inside = (cy >= 0.f) && (cy <= fh - 1.f) && (cx >= 0.f) && (cx <= fw - 1.f);
+        const float uy = grid_chain(cy, fh), ux = grid_chain(cx, fw);
+        const float fy = floorf(uy), fx = floorf(ux);
+        float wy[4], wx[4];
+        cubic_coeffs_fast(uy - fy, wy);
+        cubic_coeffs_fast(ux - fx, wx);
+        // in range by the regularity test; the clamp only keeps a NaN/garbage coordinate
+        // from reading outside the LDS tile
+        int ly = (int)fy - 1 - wy0, lx = (int)fx - 1 - ax;
+        ly = ly < 0 ? 0 : (ly > GW_ROWS - 4 ? GW_ROWS - 4 : ly);
+        lx = lx < 0 ? 0 : (lx > GW_STRIDE - 4 ? GW_STRIDE - 4 : lx);
+        const float* t0 = tile + ly * GW_STRIDE + lx;
+        float rowv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float* t = t0 + i * GW_STRIDE;
+          rowv[i] = gw_dot4(wx, t[0], t[1], t[2], t[3]);
+        }
+        float o = gw_dot4(wy, rowv[0], rowv[1], rowv[2], rowv[3]);
+        o = inside ? o : 0.f;
+        if (WRITE_FRAMES) a.out_frames[(int64_t)f * hw + (int64_t)y * w + x] = o;
+        if (WRITE_SUM) acc[r][k] += o;
+      }
+    }
+    __syncthreads();  // everyone is done with the tile before the next frame overwrites it
+  }
+  if (WRITE_SUM) {
+#pragma unroll
+    for (int r = 0; r < RIGID_ROWS; ++r) {
+      const int y = y0 + r;
+      if (y >= h) break;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int x = xt + lane + 64 * k;
+        if (x < w) a.out_sum[(int64_t)y * w + x] += acc[r][k];
+      }
+    }
+  }
+}
+
+// Tile-frames warp_field flagged as irregular: generic per-pixel gathers from global
+// memory (border padding by clipping every tap coordinate).  One workgroup per tile, so
+// the += on out_sum cannot race.
+template <bool UNIT_PS>
+__global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES) void warp_field_slow(FieldArgs fa, int write_frames,
+                                                                           int write_sum) {
+  const WarpArgs& a = fa.w;
+  const int nt = a.tiles_x * a.tiles_y;
+  const int tl = blockIdx.x;
+  bool any = false;
+  for (int f = 0; f < a.nframes; ++f) any = any || fa.flags[(int64_t)f * nt + tl];
+  if (!any) return;
+  const int tyi = tl / a.tiles_x, txi = tl - tyi * a.tiles_x;
+  const int h = a.h, w = a.w;
+  const float fh = (float)h, fw = (float)w;
+  const int64_t hw = (int64_t)h * w;
+  const int64_t chs = (int64_t)a.GH * w;
+  const int xt = txi * (RIGID_LANES * 4), yt = tyi * (RIGID_WAVES * RIGID_ROWS);
+  for (int i = threadIdx.y * RIGID_LANES + threadIdx.x; i < RIGID_LANES * 4 * RIGID_WAVES * RIGID_ROWS;
+       i += RIGID_LANES * RIGID_WAVES) {
+    const int y = yt + i / (RIGID_LANES * 4), x = xt + i % (RIGID_LANES * 4);
+    if (y >= h || x >= w) continue;
+    const int4 yt4 = *reinterpret_cast<const int4*>(a.ytap + 4 * y);
+    const float4 yc4 = *reinterpret_cast<const float4*>(a.ycoef + 4 * y);
+    float accp = 0.f;
+    for (int f = 0; f < a.nframes; ++f) {
+      if (!fa.flags[(int64_t)f * nt + tl]) continue;
+      const float* fr = a.frames + (int64_t)f * hw;
+      const float* E = a.etab + (int64_t)f * 2 * a.GH * w + x;
+      float sy = dot4(yc4, E[(int64_t)yt4.x * w], E[(int64_t)yt4.y * w], E[(int64_t)yt4.z * w],
+                      E[(int64_t)yt4.w * w]);
+      float sx = dot4(yc4, E[chs + (int64_t)yt4.x * w], E[chs + (int64_t)yt4.y * w],
+                      E[chs + (int64_t)yt4.z * w], E[chs + (int64_t)yt4.w * w]);
+      if (!UNIT_PS) {
+        sy = sy / a.pixel_spacing;
+        sx = sx / a.pixel_spacing;
+      }
+      const float cy = (float)y + sy, cx = (float)x + sx;
+      const bool inside = (cy >= 0.f) && (cy <= fh - 1.f) && (cx >= 0.f) && (cx <= fw - 1.f);
+      const float uy = grid_chain(cy, fh), ux = grid_chain(cx, fw);
+      const float fy = floorf(uy), fx = floorf(ux);
+      float wy[4], wx[4];
+      cubic_coeffs_fast(uy - fy, wy);
+      cubic_coeffs_fast(ux - fx, wx);
+      float rowv[4];
+      for (int ii = 0; ii < 4; ++ii) {
+        const float ty = fminf(fmaxf(fy + (float)(ii - 1), 0.f), fh - 1.f);
+        const float* rp = fr + (int64_t)(int)ty * w;
+        float t4[4];
+        for (int j = 0; j < 4; ++j) t4[j] = rp[(int)fminf(fmaxf(fx + (float)(j - 1), 0.f), fw - 1.f)];
+        rowv[ii] = gw_dot4(wx, t4[0], t4[1], t4[2], t4[3]);
+      }
+      float o = gw_dot4(wy, rowv[0], rowv[1], rowv[2], rowv[3]);
+      o = inside ? o : 0.f;
+      if (write_frames) a.out_frames[(int64_t)f * hw + (int64_t)y * w + x] = o;
+      accp += o;
+    }
+    if (write_sum) a.out_sum[(int64_t)y * w + x] += accp;
+  }
+}
+
 // get_pixel_shifts (correct_motion.py:132-185) for one lattice: out (h, w, 2) px.
 __global__ void warp_pixel_shifts(const float* __restrict__ etab, const int* __restrict__ ytap,
                                   const float* __restrict__ ycoef, int h, int w, int GH,
@@ -826,6 +1164,12 @@ __global__ void spline_lattice_kernel(const float* __restrict__ data, int c, int
   out[i] = vt;
 }
 
+static int64_t field_flag_bytes(int nframes, int h, int w) {
+  const int64_t tx = (w + RIGID_LANES * 4 - 1) / (RIGID_LANES * 4);
+  const int64_t ty = (h + RIGID_WAVES * RIGID_ROWS - 1) / (RIGID_WAVES * RIGID_ROWS);
+  return ((int64_t)nframes * tx * ty + 15) & ~(int64_t)15;
+}
+
 static int64_t etab_floats(int nframes, int GH, int w) {
   return (((int64_t)nframes * 2 * GH * w) + 3) & ~(int64_t)3;  // keep the int4 tables aligned
 }
@@ -846,8 +1190,8 @@ int mc_spline_lattice(const float* data, int c, int nt, int nh, int nw, const in
 
 int mc_warp_scratch_bytes(int nframes, int h, int w, int GH, int GW, int64_t* bytes) {
   if (!bytes || nframes < 1 || h < 2 || w < 2 || GH < 1 || GW < 1) return MC_ERR_ARG;
-  // etab floats + (ytap,ycoef,xtap,xcoef)
-  *bytes = (etab_floats(nframes, GH, w) + 8 * (int64_t)(h + w)) * 4;
+  // etab floats + (ytap,ycoef,xtap,xcoef) + one flag byte per (frame, 256x32 tile)
+  *bytes = (etab_floats(nframes, GH, w) + 8 * (int64_t)(h + w)) * 4 + field_flag_bytes(nframes, h, w);
   return MC_OK;
 }
 
@@ -871,10 +1215,41 @@ int mc_warp_frames(const float* frames, int nframes, int h, int w, const float* 
   a.frames = frames; a.nframes = nframes; a.h = h; a.w = w; a.GH = GH; a.etab = etab;
   a.ytap = ytap; a.ycoef = ycoef; a.pixel_spacing = pixel_spacing;
   a.out_frames = out_frames; a.out_sum = out_sum;
+  const bool unit = (pixel_spacing == 1.0f);
+  static int use_tile = -1;
+  if (use_tile < 0) {
+    const char* v = getenv("MC_WARP_TILE");
+    use_tile = v ? atoi(v) : 1;
+  }
+  if (use_tile && (w % 4 == 0) && ((((uintptr_t)frames) & 15) == 0)) {
+    a.tiles_x = (w + RIGID_LANES * 4 - 1) / (RIGID_LANES * 4);
+    a.tiles_y = (h + RIGID_WAVES * RIGID_ROWS - 1) / (RIGID_WAVES * RIGID_ROWS);
+    FieldArgs fa;
+    fa.w = a;
+    fa.lattice = lattice;
+    fa.xtap = xtap;
+    fa.GW = GW;
+    fa.flags = reinterpret_cast<unsigned char*>(xcoef + 4 * (int64_t)w);
+    hipError_t e = hipMemsetAsync(fa.flags, 0, (size_t)field_flag_bytes(nframes, h, w), s);
+    if (e != hipSuccess) return (int)e;
+    dim3 grid(a.tiles_x * a.tiles_y), block(RIGID_LANES, RIGID_WAVES);
+    const size_t lds = (size_t)GW_QUADS_PAD * 16;
+#define MC_GW_LAUNCH(F, S)                                                                  \
+  do {                                                                                      \
+    if (unit) hipLaunchKernelGGL((warp_field<F, S, true>), grid, block, lds, s, fa);        \
+    else hipLaunchKernelGGL((warp_field<F, S, false>), grid, block, lds, s, fa);            \
+  } while (0)
+    if (out_frames && out_sum) MC_GW_LAUNCH(true, true);
+    else if (out_frames) MC_GW_LAUNCH(true, false);
+    else MC_GW_LAUNCH(false, true);
+#undef MC_GW_LAUNCH
+    if (unit) hipLaunchKernelGGL((warp_field_slow<true>), grid, block, 0, s, fa, out_frames ? 1 : 0, out_sum ? 1 : 0);
+    else hipLaunchKernelGGL((warp_field_slow<false>), grid, block, 0, s, fa, out_frames ? 1 : 0, out_sum ? 1 : 0);
+    return mc_check_launch();
+  }
   a.tiles_x = (w + WARP_TX * WARP_PX - 1) / (WARP_TX * WARP_PX);
   a.tiles_y = (h + WARP_TY * WARP_ROWS - 1) / (WARP_TY * WARP_ROWS);
   dim3 grid(a.tiles_x * a.tiles_y), block(WARP_TX, WARP_TY);
-  const bool unit = (pixel_spacing == 1.0f);
 #define MC_WARP_LAUNCH(F, S)                                                     \
   do {                                                                           \
     if (unit) hipLaunchKernelGGL((warp_main<F, S, true>), grid, block, 0, s, a); \
