@@ -101,8 +101,8 @@ int mc_xc_cols_inverse(const void* S_cur, const int* cur_idx, const void* S_ref,
 
 /* K4+K5.  Inverse real row FFT of T2 fused with the arg-max (first maximum, as
  * torch.argmax): peaks[p] = flat index y*W+x, shifts[p] = (sy,sx) after the
- * wrap-around rule `p if p <= n//2 else p-n`.  part_val: scratch of npairs*(H/RG)
- * floats; part_idx: scratch of npairs*(H/RG) + npairs ints.  The search is an exact
+ * wrap-around rule `p if p <= n//2 else p-n`.  part_val: scratch of npairs*(H/RG) +
+ * npairs*H floats; part_idx: scratch of npairs*(H/RG) + npairs ints.  The search is an exact
  * branch and bound: row groups whose triangle-inequality bound cannot reach the best
  * value found so far are skipped.  estimate_motion_xc.py:113-121 / :350-355,368-369. */
 int mc_xc_rows_inverse_argmax(const void* T2, float* part_val, int* part_idx, int* peaks,

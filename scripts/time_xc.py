@@ -18,7 +18,7 @@ cur = torch.tensor([f for f in range(t) if f != 20], device=dev, dtype=torch.int
 ref = torch.full_like(cur, 20)
 T2 = torch.empty((npairs, gm.nkx, gm.H, 2), device=dev)
 ngrp = gm.H // gm.RG
-pv = torch.empty(npairs * ngrp, device=dev); pi = torch.empty(npairs * ngrp + npairs, device=dev, dtype=torch.int32)
+pv = torch.empty(npairs * ngrp + npairs * gm.H, device=dev); pi = torch.empty(npairs * ngrp + npairs, device=dev, dtype=torch.int32)
 peaks = torch.empty(npairs, device=dev, dtype=torch.int32); sh = torch.empty((npairs, 2), device=dev)
 st = stream_ptr(dev)
 def k0(): engine.central_box_stats(stack)

@@ -286,8 +286,24 @@ __device__ __forceinline__ int float_order(float f) {  // order-preserving float
   return i >= 0 ? i : i ^ 0x7fffffff;
 }
 
+// bounds[p][y] = |X[0]| + 2 * sum_{k>=1} |X[k]|,  X = T2[p][.][y]  (coalesced over y)
+__global__ __launch_bounds__(256) void xc_row_bounds(const cfloat* __restrict__ T2,
+                                                     float* __restrict__ bounds, int nkx, int H) {
+  const int y = blockIdx.x * 256 + threadIdx.x;
+  const int p = blockIdx.y;
+  if (y >= H) return;
+  const cfloat* in = T2 + (int64_t)p * nkx * H + y;
+  float b = 0.f;
+  for (int kx = 0; kx < nkx; ++kx) {
+    const cfloat v = in[(int64_t)kx * H];
+    b += (kx == 0 ? 1.f : 2.f) * sqrtf(v.x * v.x + v.y * v.y);
+  }
+  bounds[(int64_t)p * H + y] = b;
+}
+
 template <int LOGN, int EPI>
 __global__ __launch_bounds__(MC_WG) void xc_rows_inv(const cfloat* __restrict__ T2,
+                                                     const float* __restrict__ bounds,
                                                      int* __restrict__ best,
                                                      float* __restrict__ part_val,
                                                      int* __restrict__ part_idx,
@@ -313,39 +329,24 @@ __global__ __launch_bounds__(MC_WG) void xc_rows_inv(const cfloat* __restrict__ 
   int grp = blockIdx.x;
   if (EPI == 0) grp = phase == 0 ? ((int)blockIdx.x < near ? (int)blockIdx.x : ngrp - 2 * near + (int)blockIdx.x)
                                  : near + (int)blockIdx.x;
-  const cfloat* in = T2 + (int64_t)p * g.nkx * g.H + (int64_t)grp * RG;
-  float bound = 0.f;
-  for (int i = tid; i < g.nkx * RG; i += MC_WG) {
-    const int kx = i / RG, r = i - kx * RG;
-    const cfloat v = in[(int64_t)kx * g.H + r];
-    stg[kx * (RG + 1) + r] = v;
-    if (EPI == 0) bound += (kx == 0 ? 1.f : 2.f) * sqrtf(v.x * v.x + v.y * v.y);
-  }
   if constexpr (EPI == 0) {
-    // per-row bounds: element i belongs to row i % RG = tid % RG (RG divides 256), so
-    // lanes with equal lane % RG hold partial sums of the same row
-    for (int off = 32; off >= RG; off >>= 1) bound += __shfl_xor(bound, off);
-    __shared__ float wb[MC_WG / 64][16];
-    __shared__ int skip;
-    if ((tid & 63) < RG) wb[tid >> 6][tid & 63] = bound;
-    __syncthreads();
-    if (tid == 0) {
+    if (phase == 1) {  // wave-uniform early exit: nothing of T2 is read for a skipped group
       float b = 0.f;
-      for (int r = 0; r < RG; ++r) {
-        float br = 0.f;
-        for (int w = 0; w < MC_WG / 64; ++w) br += wb[w][r];
-        b = fmaxf(b, br);
-      }
+      for (int r = 0; r < RG; ++r) b = fmaxf(b, bounds[(int64_t)p * g.H + grp * RG + r]);
       b = b * 1.0001f + 1e-30f;  // rounding slack of the transform itself
-      skip = phase == 1 &&
-             float_order(b) < __hip_atomic_load(&best[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (skip) {
-        part_val[(int64_t)p * ngrp + grp] = -INFINITY;
-        part_idx[(int64_t)p * ngrp + grp] = 0x7fffffff;
+      if (float_order(b) < __hip_atomic_load(&best[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        if (tid == 0) {
+          part_val[(int64_t)p * ngrp + grp] = -INFINITY;
+          part_idx[(int64_t)p * ngrp + grp] = 0x7fffffff;
+        }
+        return;
       }
     }
-    __syncthreads();
-    if (skip) return;
+  }
+  const cfloat* in = T2 + (int64_t)p * g.nkx * g.H + (int64_t)grp * RG;
+  for (int i = tid; i < g.nkx * RG; i += MC_WG) {
+    const int kx = i / RG, r = i - kx * RG;
+    stg[kx * (RG + 1) + r] = in[(int64_t)kx * g.H + r];
   }
   FftTwiddles<N> T;
   T.template init<+1>(lt, tw_row, 2);
@@ -675,17 +676,21 @@ int mc_xc_rows_inverse_argmax(const void* T2, float* part_val, int* part_idx, in
   }
   int near = (64 + g.RG - 1) / g.RG;  // groups covering |shift_y| <= 64 px at each end
   if (2 * near > ngrp) near = ngrp / 2;
+  float* bounds = part_val + (int64_t)npairs * ngrp;  // npairs * H row bounds
+  if (ngrp - 2 * near > 0)
+    hipLaunchKernelGGL(xc_row_bounds, dim3((g.H + 255) / 256, npairs), dim3(256), 0, (hipStream_t)stream,
+                       (const cfloat*)T2, bounds, g.nkx, g.H);
   MC_DISPATCH_LOG(logn, {
     auto k = xc_rows_inv<L, 0>;
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (near > 0)
       hipLaunchKernelGGL(k, dim3(2 * near, npairs), dim3(MC_WG), lds, (hipStream_t)stream,
-                         (const cfloat*)T2, best, part_val, part_idx, (float*)nullptr,
+                         (const cfloat*)T2, (const float*)bounds, best, part_val, part_idx, (float*)nullptr,
                          (const int64_t*)nullptr, (int64_t)0, (const cfloat*)tw_row, g, near, 0);
     if (ngrp - 2 * near > 0)
       hipLaunchKernelGGL(k, dim3(ngrp - 2 * near, npairs), dim3(MC_WG), lds, (hipStream_t)stream,
-                         (const cfloat*)T2, best, part_val, part_idx, (float*)nullptr,
+                         (const cfloat*)T2, (const float*)bounds, best, part_val, part_idx, (float*)nullptr,
                          (const int64_t*)nullptr, (int64_t)0, (const cfloat*)tw_row, g, near, 1);
   });
   rc = mc_check_launch();
@@ -711,7 +716,7 @@ int mc_xc_rows_inverse_store(const void* T2, float* out, const int64_t* out_off,
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, grid, dim3(MC_WG), lds, (hipStream_t)stream, (const cfloat*)T2,
-                       (int*)nullptr, (float*)nullptr, (int*)nullptr, out, out_off, out_stride,
+                       (const float*)nullptr, (int*)nullptr, (float*)nullptr, (int*)nullptr, out, out_off, out_stride,
                        (const cfloat*)tw_row, g, 0, 0);
   });
   return mc_check_launch();

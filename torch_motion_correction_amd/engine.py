@@ -98,7 +98,7 @@ def _peaks(S_cur, cur_idx, S_ref, ref_idx, pl, want_nbhd):
     chunk = max(1, min(npairs, WORKSPACE_BYTES // per_pair))
     T2 = torch.empty((chunk, g.nkx, g.H, 2), dtype=torch.float32, device=dev)
     ngrp = g.H // g.RG
-    pv = torch.empty(chunk * ngrp, dtype=torch.float32, device=dev)
+    pv = torch.empty(chunk * ngrp + chunk * g.H, dtype=torch.float32, device=dev)
     pi = torch.empty(chunk * ngrp + chunk, dtype=torch.int32, device=dev)
     st = stream_ptr(dev)
     scale = 1.0 / (g.H * g.W)
