@@ -59,7 +59,7 @@ def main():
     ap.add_argument("--frames", type=int, default=40)
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=6)
+    ap.add_argument("--cpu-frames", type=int, default=4)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -175,7 +175,7 @@ def main():
                 "shifts_match_ground_truth": shifts_ok,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "warp_rigid", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "bound": "hbm", "kernel": "warp_rigid_dma", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "ms_per_launch": warp_ms, "algorithmic_bytes_per_launch": alg_bytes,
             },

@@ -286,19 +286,35 @@ __device__ __forceinline__ int float_order(float f) {  // order-preserving float
   return i >= 0 ? i : i ^ 0x7fffffff;
 }
 
-// bounds[p][y] = |X[0]| + 2 * sum_{k>=1} |X[k]|,  X = T2[p][.][y]  (coalesced over y)
+// bounds[p][y] = |X[0]| + 2 * sum_{k>=1} |X[k]|,  X = T2[p][.][y].  Workgroup = 64 rows x
+// 4 interleaved kx slices (coalesced 512-byte reads over y, 4 loads in flight per thread).
 __global__ __launch_bounds__(256) void xc_row_bounds(const cfloat* __restrict__ T2,
                                                      float* __restrict__ bounds, int nkx, int H) {
-  const int y = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float part[4][64];
+  const int ly = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int y = blockIdx.x * 64 + ly;
   const int p = blockIdx.y;
-  if (y >= H) return;
-  const cfloat* in = T2 + (int64_t)p * nkx * H + y;
-  float b = 0.f;
-  for (int kx = 0; kx < nkx; ++kx) {
-    const cfloat v = in[(int64_t)kx * H];
-    b += (kx == 0 ? 1.f : 2.f) * sqrtf(v.x * v.x + v.y * v.y);
+  float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+  if (y < H) {
+    const cfloat* in = T2 + (int64_t)p * nkx * H + y;
+    int kx = slice;
+    for (; kx + 12 < nkx; kx += 16) {
+      const cfloat v0 = in[(int64_t)kx * H], v1 = in[(int64_t)(kx + 4) * H];
+      const cfloat v2 = in[(int64_t)(kx + 8) * H], v3 = in[(int64_t)(kx + 12) * H];
+      b0 += (kx == 0 ? 1.f : 2.f) * sqrtf(v0.x * v0.x + v0.y * v0.y);
+      b1 += 2.f * sqrtf(v1.x * v1.x + v1.y * v1.y);
+      b2 += 2.f * sqrtf(v2.x * v2.x + v2.y * v2.y);
+      b3 += 2.f * sqrtf(v3.x * v3.x + v3.y * v3.y);
+    }
+    for (; kx < nkx; kx += 4) {
+      const cfloat v = in[(int64_t)kx * H];
+      b0 += (kx == 0 ? 1.f : 2.f) * sqrtf(v.x * v.x + v.y * v.y);
+    }
   }
-  bounds[(int64_t)p * H + y] = b;
+  part[slice][ly] = (b0 + b1) + (b2 + b3);
+  __syncthreads();
+  if (slice == 0 && y < H)
+    bounds[(int64_t)p * H + y] = (part[0][ly] + part[1][ly]) + (part[2][ly] + part[3][ly]);
 }
 
 template <int LOGN, int EPI>
@@ -678,7 +694,7 @@ int mc_xc_rows_inverse_argmax(const void* T2, float* part_val, int* part_idx, in
   if (2 * near > ngrp) near = ngrp / 2;
   float* bounds = part_val + (int64_t)npairs * ngrp;  // npairs * H row bounds
   if (ngrp - 2 * near > 0)
-    hipLaunchKernelGGL(xc_row_bounds, dim3((g.H + 255) / 256, npairs), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(xc_row_bounds, dim3((g.H + 63) / 64, npairs), dim3(256), 0, (hipStream_t)stream,
                        (const cfloat*)T2, bounds, g.nkx, g.H);
   MC_DISPATCH_LOG(logn, {
     auto k = xc_rows_inv<L, 0>;
