@@ -189,6 +189,36 @@ int mc_xc_rows_inverse_store(const void* T2, float* out, const int64_t* out_off,
                              int64_t out_stride, const void* tw_row, int nframes,
                              const mc_xc_geom* geom, void* stream);
 
+/* ---- generic transform lengths (Bluestein): any even W (rows), any H (columns) ------ */
+/* One line plan (host struct of device pointers): tw_m = exp(-2 pi i k/M) (M entries),
+ * chirp = exp(-+ i pi j^2/n) (n entries; - for forward, + for inverse transforms),
+ * bspec = FFT_M(wrapped conj(chirp)) / M (M entries); M = power of two >= 2n-1, <= 8192.
+ * n is W/2 for the row functions and H for the column functions. */
+typedef struct mc_xc_line {
+  const void* tw_m;
+  const void* chirp;
+  const void* bspec;
+  int M;
+} mc_xc_line;
+
+/* Same contracts and layouts as mc_xc_rows_forward / mc_xc_cols_forward /
+ * mc_xc_cols_inverse (+ Fourier-shift mode when `shifts` != NULL) /
+ * mc_xc_rows_inverse_argmax (out == NULL) and mc_xc_rows_inverse_store (out != NULL),
+ * without the power-of-two restriction: 4 <= W <= 8192 even, 2 <= H <= 4096.
+ * tw_row = exp(-2 pi i k / W), W entries. */
+int mc_xcg_rows_forward(const float* src, const int64_t* job_off, int64_t row_stride,
+                        const int* job_expo, const float* mask, const float* mean_rstd, void* T1,
+                        const void* tw_row, const mc_xc_line* line, int njobs,
+                        const mc_xc_geom* geom, void* stream);
+int mc_xcg_cols_forward(const void* T1, const float* filt, void* S, const mc_xc_line* line,
+                        int njobs, const mc_xc_geom* geom, void* stream);
+int mc_xcg_cols_inverse(const void* S_cur, const int* cur_idx, const void* S_ref,
+                        const int* ref_idx, const float* shifts, void* T2, const mc_xc_line* line,
+                        float scale, int npairs, const mc_xc_geom* geom, void* stream);
+int mc_xcg_rows_inverse(const void* T2, float* part_val, int* part_idx, int* peaks, float* shifts,
+                        float* out, const int64_t* out_off, int64_t out_stride, const void* tw_row,
+                        const mc_xc_line* line, int npairs, const mc_xc_geom* geom, void* stream);
+
 /* caller-side frame sum (examples/ttMotion.py:398): sum[h*w] = sum_t frames[t]. */
 int mc_sum_frames(const float* frames, int nframes, int64_t hw, float* sum, void* stream);
 

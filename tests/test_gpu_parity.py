@@ -474,3 +474,52 @@ def test_rigid_warp_odd_widths(mc, dev, shape):
     assert_frames_close(got, ref, knife_edge_mask(img, fld, 1.2, "catmull_rom", eps=2e-3), max_excluded=0.05)
     total = mc.motion_correct_sum(img.to(dev), fld.to(dev), 1.2).cpu()
     assert float((total - got.cpu().sum(0)).abs().max()) <= 1e-4
+
+
+# ------------------------------------------------------------------ non-power-of-two frames
+
+
+@pytest.mark.parametrize("t,h,w,ps", [(6, 96, 120, 1.0), (5, 100, 64, 1.0), (4, 64, 100, 1.3),
+                                      (5, 250, 372, 1.0), (3, 124, 126, 0.9)])
+def test_global_estimate_on_arbitrary_even_sizes(mc, dev, t, h, w, ps):
+    """chirp-z rows and/or columns: integer shifts must equal the oracle's exactly"""
+    st, _, _ = drift_stack(t, h, w, seed=h * 7 + w)
+    got = mc.estimate_global_motion(st.to(dev), ps).cpu()
+    ref, ccs = oracle.estimate_global_motion(st, ps, return_cc=True)
+    for f, cc in ccs.items():
+        top = torch.topk(cc.flatten(), 2).values
+        if float(top[0] - top[1]) > 1e-5 * float(top[0].abs()):  # skip oracle near-ties
+            assert torch.equal(got[:, f], ref[:, f]), (f, got[:, f].flatten(), ref[:, f].flatten())
+
+
+def test_pruned_spectrum_on_arbitrary_sizes(dev):
+    from torch_motion_correction_amd import engine, plan
+
+    g = torch.Generator().manual_seed(31)
+    h, w = 100, 120
+    img = torch.randn(3, h, w, generator=g)
+    pl = plan.get_xc_plan(h, w, 1.0, 500.0, (300, 10), dev)
+    gm = pl.geom
+    d = img.to(dev)
+    off = torch.arange(3, device=dev, dtype=torch.int64) * (h * w)
+    S = torch.view_as_complex(engine._forward_spectra(d, off, w, None, pl, engine.central_box_stats(d)).cpu())
+    spec = (torch.fft.rfftn(oracle.normalize_image(img) * tp.circle(min(h, w) / 4, (h, w), smoothing_radius=min(h, w) / 8),
+                            dim=(-2, -1)) * oracle.prepare_bandpass_filter((300, 10), (h, w), 1.0)
+            * tp.b_envelope(500, (h, w), 1.0))
+    rows = list(range(gm.kyp)) + list(range(h - gm.kyn, h))
+    sub = spec[:, rows][:, :, : gm.nkx].transpose(1, 2)
+    assert float((S - sub).abs().max() / sub.abs().max()) <= 5e-6
+
+
+@pytest.mark.parametrize("shape", [(3, 100, 66), (2, 96, 120), (2, 64, 90)])
+def test_correct_motion_fast_on_arbitrary_sizes(mc, dev, shape):
+    g = torch.Generator().manual_seed(sum(shape))
+    img = torch.randn(*shape, generator=g)
+    sh = torch.randn(2, shape[0], 1, 1, generator=g) * 3
+    assert rel_err(mc.correct_motion_fast(img.to(dev), sh.clone().to(dev)),
+                   oracle.correct_motion_fast(img, sh.clone())) <= 2e-5
+
+
+def test_odd_width_is_rejected_loudly(mc, dev):
+    with pytest.raises(NotImplementedError, match="even widths"):
+        mc.estimate_global_motion(torch.randn(3, 64, 65, device=dev), 1.0)

@@ -98,8 +98,30 @@ def test_full_geometry_keeps_everything():
 
 
 def test_unsupported_sizes_fail_loudly():
-    with pytest.raises(NotImplementedError, match="power-of-two"):
-        plan.xc_geometry(4092, 5760, 0.1, 1000, 500)
+    with pytest.raises(NotImplementedError, match="even widths"):
+        plan.xc_geometry(4092, 5761, 0.1, 1000, 500)  # odd width
+    with pytest.raises(NotImplementedError, match="even widths"):
+        plan.xc_geometry(8184, 11520, 0.1, 2000, 1000)  # beyond the 8192 x 4096 limit
+    with pytest.raises(NotImplementedError, match="M="):
+        plan.line_plan(5760, -1, "cpu")
+
+
+def test_k3_geometry_and_chirp_tables():
+    """BASELINE config 3 frames (4092 x 5760) go through the chirp-z path."""
+    low, high = plan.band_limits((300, 10), 1.0)
+    g = plan.xc_geometry(4092, 5760, high, 1023.0, 511.5)
+    assert (g.nkx, g.kyp, g.kyn) == (577, 410, 409) and 4092 % g.RG == 0 and g.ny % g.RG == 0
+    line, (tw, chirp, bspec) = plan.line_plan(12, -1, "cpu")
+    assert line.M == 32 and chirp.shape == (12, 2) and bspec.shape == (32, 2)
+    # chirp-z identity on the host: DFT_12(x) == c * ifft(fft(x*c, 32) * B)[:12] * 32 (B holds 1/32)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(12) + 1j * rng.standard_normal(12)
+    c = chirp.numpy()[:, 0] + 1j * chirp.numpy()[:, 1]
+    B = bspec.numpy()[:, 0] + 1j * bspec.numpy()[:, 1]
+    a = np.zeros(32, complex)
+    a[:12] = x * c
+    X = c * (np.fft.ifft(np.fft.fft(a) * B) * 32)[:12]
+    assert np.allclose(X, np.fft.fft(x), atol=1e-5)
 
 
 def test_band_limits_follow_reference_ops():

@@ -27,7 +27,14 @@ class XcGeom(C.Structure):
         return self.kyp + self.kyn
 
 
+class XcLine(C.Structure):
+    """mirror of ``mc_xc_line`` (Bluestein line plan: device pointers + M)"""
+
+    _fields_ = [("tw_m", C.c_void_p), ("chirp", C.c_void_p), ("bspec", C.c_void_p), ("M", C.c_int)]
+
+
 GP = C.POINTER(XcGeom)
+LP = C.POINTER(XcLine)
 
 # name -> argtypes; every function returns int
 SIGNATURES = {
@@ -55,6 +62,10 @@ SIGNATURES = {
     "mc_pixel_shifts": [vp, i32, i32, i32, i32, f32, vp, vp, vp],
     "mc_fourier_shift_cols_inverse": [vp, vp, vp, vp, vp, f32, i32, GP, vp],
     "mc_xc_rows_inverse_store": [vp, vp, vp, i64, vp, i32, GP, vp],
+    "mc_xcg_rows_forward": [vp, vp, i64, vp, vp, vp, vp, vp, LP, i32, GP, vp],
+    "mc_xcg_cols_forward": [vp, vp, vp, LP, i32, GP, vp],
+    "mc_xcg_cols_inverse": [vp, vp, vp, vp, vp, vp, LP, f32, i32, GP, vp],
+    "mc_xcg_rows_inverse": [vp, vp, vp, vp, vp, vp, vp, i64, vp, LP, i32, GP, vp],
     "mc_sum_frames": [vp, i32, i64, vp, vp],
 }
 

@@ -281,7 +281,9 @@ __device__ __forceinline__ void fft_pass(int tid, const cfloat* __restrict__ tw,
   if (SYNC_END) __syncthreads();
 }
 
-template <int N, int NS, int DIR, bool FIRST, typename Load, typename Store>
+// FIRST_LDS: the first pass's `load` reads the line itself, so its reads must be fenced
+// from its writes like any later pass.
+template <int N, int NS, int DIR, bool FIRST, bool FIRST_LDS = false, typename Load, typename Store>
 __device__ __forceinline__ void fft_rec(cfloat* line, int tid, const cfloat* __restrict__ tw,
                                         int tw_stride, Load load, Store store) {
   constexpr int REM = N / NS;
@@ -290,9 +292,9 @@ __device__ __forceinline__ void fft_rec(cfloat* line, int tid, const cfloat* __r
   auto lds_load = [line](int i) { return line[lpad(i)]; };
   auto lds_store = [line](int i, cfloat v) { line[lpad(i)] = v; };
   if constexpr (FIRST && LAST) {
-    fft_pass<N, R, NS, DIR, false, false>(tid, tw, tw_stride, load, store);
+    fft_pass<N, R, NS, DIR, FIRST_LDS, false>(tid, tw, tw_stride, load, store);
   } else if constexpr (FIRST) {
-    fft_pass<N, R, NS, DIR, false, true>(tid, tw, tw_stride, load, lds_store);
+    fft_pass<N, R, NS, DIR, FIRST_LDS, true>(tid, tw, tw_stride, load, lds_store);
     fft_rec<N, NS * R, DIR, false>(line, tid, tw, tw_stride, load, store);
   } else if constexpr (LAST) {
     fft_pass<N, R, NS, DIR, true, false>(tid, tw, tw_stride, lds_load, store);
@@ -312,4 +314,34 @@ template <int N, int DIR, typename Load, typename Store>
 __device__ __forceinline__ void wg_fft(cfloat* line, int tid, const cfloat* __restrict__ tw,
                                        int tw_stride, Load load, Store store) {
   fft_rec<N, 1, DIR, true>(line, tid, tw, tw_stride, load, store);
+}
+
+// Same, but the inputs already sit in `line` (natural order): load(i) must read line[lpad(i)].
+template <int N, int DIR, typename Load, typename Store>
+__device__ __forceinline__ void wg_fft_inplace(cfloat* line, int tid, const cfloat* __restrict__ tw,
+                                               int tw_stride, Load load, Store store) {
+  fft_rec<N, 1, DIR, true, true>(line, tid, tw, tw_stride, load, store);
+}
+
+// Bluestein chirp-z: a length-n DFT (any n, 2n-1 <= M = power of two) of x as
+//   X[k] = c[k] * ( (x .* c) (*) conj(c) )[k],   c[j] = exp(DIR * i*pi*j^2/n)
+// with the convolution done by two length-M transforms in `line`.  chirp = c for this
+// direction (n entries), bspec = FFT_M of the wrapped conj(c) (M entries, already scaled
+// by 1/M).  load(j) -> x[j] for j < n (each j once); store(k, X[k]) is called for every
+// k < M, the caller keeps the k it needs (k < n).  Every thread of the workgroup must call
+// it; `line` must be free on entry; on exit a barrier is still needed before reusing `line`.
+template <int M, typename Load, typename Store>
+__device__ __forceinline__ void wg_bluestein(cfloat* line, int tid, const cfloat* __restrict__ tw_m,
+                                             const cfloat* __restrict__ chirp,
+                                             const cfloat* __restrict__ bspec, int n, Load load,
+                                             Store store) {
+  auto in1 = [&](int j) { return j < n ? cmul(load(j), chirp[j]) : cmake(0.f, 0.f); };
+  auto out1 = [&](int j, cfloat v) { line[lpad(j)] = cmul(v, bspec[j]); };
+  wg_fft<M, -1>(line, tid, tw_m, 1, in1, out1);
+  __syncthreads();
+  auto in2 = [&](int j) { return line[lpad(j)]; };
+  auto out2 = [&](int k, cfloat v) {
+    if (k < n) store(k, cmul(v, chirp[k]));
+  };
+  wg_fft_inplace<M, +1>(line, tid, tw_m, 1, in2, out2);
 }

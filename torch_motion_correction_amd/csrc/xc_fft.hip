@@ -534,15 +534,17 @@ __global__ __launch_bounds__(MC_WG) void xc_peak_nbhd(const cfloat* __restrict__
       return MC_ERR_UNSUPPORTED;            \
   }
 
-static int geom_from(const mc_xc_geom* q, XcGeom* g) {
+// rows_pow2 / cols_pow2: which dimension the calling kernel transforms with the
+// power-of-two FFT (the other one may be any length handled by the chirp-z kernels)
+static int geom_from(const mc_xc_geom* q, XcGeom* g, bool rows_pow2 = true, bool cols_pow2 = true) {
   if (!q) return MC_ERR_ARG;
-  if (!mc_is_pow2(q->W) || !mc_is_pow2(q->H) || q->W < 32 || q->W > 8192 || q->H < 16 ||
-      q->H > 4096)
-    return MC_ERR_UNSUPPORTED;
+  if (q->W < 4 || (q->W & 1) || q->W > 8192 || q->H < 2 || q->H > 4096) return MC_ERR_UNSUPPORTED;
+  if (rows_pow2 && (!mc_is_pow2(q->W) || q->W < 32)) return MC_ERR_UNSUPPORTED;
+  if (cols_pow2 && (!mc_is_pow2(q->H) || q->H < 16)) return MC_ERR_UNSUPPORTED;
   if (q->nkx < 1 || q->nkx > q->W / 2 + 1) return MC_ERR_ARG;
   if (q->kyp < 0 || q->kyn < 0 || q->kyp + q->kyn < 1 || q->kyp + q->kyn > q->H) return MC_ERR_ARG;
   if (q->RG < 1 || q->ny < 1 || q->ny % q->RG || q->H % q->RG) return MC_ERR_ARG;
-  if (q->RG % (MC_WG / fft_threads(q->W / 2))) return MC_ERR_ARG;  // rows per group vs sub-groups
+  if (rows_pow2 && (q->RG % (MC_WG / fft_threads(q->W / 2)))) return MC_ERR_ARG;  // rows vs sub-groups
   if (q->y0 < 0 || q->y0 + q->ny > q->H) return MC_ERR_ARG;
   if (q->x0 < 0 || q->x1 > q->W || (q->x0 & 1) || (q->x1 & 1) || q->x0 >= q->x1) return MC_ERR_ARG;
   g->W = q->W; g->H = q->H; g->nkx = q->nkx; g->kyp = q->kyp; g->kyn = q->kyn;
@@ -559,7 +561,7 @@ extern "C" {
 
 int mc_xc_rows_lds_bytes(const mc_xc_geom* q) {
   XcGeom g;
-  int rc = geom_from(q, &g);
+  int rc = geom_from(q, &g, true, false);
   if (rc) return rc;
   return (int)rows_lds_bytes(g.W / 2, g);
 }
@@ -569,7 +571,7 @@ static int rows_forward_impl(const float* src, const int64_t* job_off, int64_t r
                              void* T1, const void* tw_row, int njobs, const mc_xc_geom* q,
                              const XcBox* box, double* stats_acc, void* stream) {
   XcGeom g;
-  int rc = geom_from(q, &g);
+  int rc = geom_from(q, &g, true, false);
   if (rc) return rc;
   if (!src || !job_off || !T1 || !tw_row || njobs < 1) return MC_ERR_ARG;
   const int logn = mc_ilog2(g.W) - 1;
@@ -624,7 +626,7 @@ int mc_xc_cols_forward_fix(const void* T1, const float* filt, void* S, const voi
                            int njobs, const mc_xc_geom* q, const float* fix, const void* Mhat,
                            void* stream) {
   XcGeom g;
-  int rc = geom_from(q, &g);
+  int rc = geom_from(q, &g, false, true);
   if (rc) return rc;
   if (!T1 || !S || !tw_col || njobs < 1 || (fix && !Mhat)) return MC_ERR_ARG;
   dim3 grid(g.nkx, njobs);
@@ -640,7 +642,7 @@ int mc_xc_cols_inverse(const void* S_cur, const int* cur_idx, const void* S_ref,
                        const int* ref_idx, void* T2, const void* tw_col, float scale, int npairs,
                        const mc_xc_geom* q, void* stream) {
   XcGeom g;
-  int rc = geom_from(q, &g);
+  int rc = geom_from(q, &g, false, true);
   if (rc) return rc;
   if (!S_cur || !cur_idx || !S_ref || !ref_idx || !T2 || !tw_col || npairs < 1) return MC_ERR_ARG;
   dim3 grid(g.nkx, npairs);
@@ -656,7 +658,7 @@ int mc_fourier_shift_cols_inverse(const void* S, const int* idx, const float* sh
                                   const void* tw_col, float scale, int nframes,
                                   const mc_xc_geom* q, void* stream) {
   XcGeom g;
-  int rc = geom_from(q, &g);
+  int rc = geom_from(q, &g, false, true);
   if (rc) return rc;
   if (!S || !idx || !shifts || !T2 || !tw_col || nframes < 1) return MC_ERR_ARG;
   dim3 grid(g.nkx, nframes);
@@ -673,7 +675,7 @@ int mc_xc_rows_inverse_argmax(const void* T2, float* part_val, int* part_idx, in
                               void* stream) {
   // part_idx holds npairs*(H/RG) candidates followed by npairs running maxima
   XcGeom g;
-  int rc = geom_from(q, &g);
+  int rc = geom_from(q, &g, true, false);
   if (rc) return rc;
   if (!T2 || !part_val || !part_idx || !peaks || !shifts || !tw_row || npairs < 1)
     return MC_ERR_ARG;
@@ -720,7 +722,7 @@ int mc_xc_rows_inverse_store(const void* T2, float* out, const int64_t* out_off,
                              int64_t out_stride, const void* tw_row, int nframes,
                              const mc_xc_geom* q, void* stream) {
   XcGeom g;
-  int rc = geom_from(q, &g);
+  int rc = geom_from(q, &g, true, false);
   if (rc) return rc;
   if (!T2 || !out || !out_off || !tw_row || nframes < 1) return MC_ERR_ARG;
   const int logn = mc_ilog2(g.W) - 1;
@@ -741,7 +743,7 @@ int mc_xc_rows_inverse_store(const void* T2, float* out, const int64_t* out_off,
 int mc_xc_peak_neighbourhood(const void* T2, const int* peaks, float* nb, const void* tw_row,
                              int npairs, const mc_xc_geom* q, void* stream) {
   XcGeom g;
-  int rc = geom_from(q, &g);
+  int rc = geom_from(q, &g, true, false);
   if (rc) return rc;
   if (!T2 || !peaks || !nb || !tw_row || npairs < 1) return MC_ERR_ARG;
   const int logn = mc_ilog2(g.W) - 1;
@@ -750,6 +752,417 @@ int mc_xc_peak_neighbourhood(const void* T2, const int* peaks, float* nb, const 
     hipLaunchKernelGGL(xc_peak_nbhd<L>, grid, dim3(MC_WG), 0, (hipStream_t)stream,
                        (const cfloat*)T2, peaks, nb, (const cfloat*)tw_row, g);
   });
+  return mc_check_launch();
+}
+
+}  // extern "C"
+
+// =====================================================================================
+// Generic transform lengths (Bluestein chirp-z on the power-of-two workgroup FFT).
+// Rows: any EVEN W (real rows are packed into W/2 complex points as in the power-of-two
+// path); columns: any H.  Same pruning, same fused prologues/epilogues, same layouts
+// (T1, S, T2); one line per workgroup pass, two length-M transforms per line, M the power
+// of two >= 2n-1.  Used for whole-frame transforms of non-power-of-two detectors (K3:
+// 4092 x 5760).  Tables per (n, direction): chirp[n] = exp(-+ i pi j^2 / n),
+// bspec[M] = FFT_M(wrapped conj chirp) / M  (host, double precision, plan.py).
+// =====================================================================================
+struct XcLine {
+  const cfloat* tw_m;   // exp(-2 pi i k / M), M entries
+  const cfloat* chirp;  // n entries
+  const cfloat* bspec;  // M entries
+  int n;                // transform length (W/2 for rows, H for columns)
+};
+
+template <int LOGM>
+__global__ __launch_bounds__(MC_WG) void xcg_rows_fwd(
+    const float* __restrict__ src, const int64_t* __restrict__ job_off, int64_t row_stride,
+    const int* __restrict__ job_expo, const float* __restrict__ mask,
+    const float* __restrict__ mean_rstd, cfloat* __restrict__ T1,
+    const cfloat* __restrict__ tw_row, XcLine ln, XcGeom g) {
+  constexpr int M = 1 << LOGM;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cfloat* line = reinterpret_cast<cfloat*>(smem);
+  cfloat* zlo = line + lds_len(M);       // Z[k], k < nkx
+  cfloat* zhi = zlo + (g.nkx + 1);       // Z[n-k] at index k, 1 <= k <= nkx
+  cfloat* stg = zhi + (g.nkx + 1);
+  const int tid = threadIdx.x;
+  const int job = blockIdx.x, grp = blockIdx.y;
+  const int RG = g.RG, n = ln.n;
+  const float mean = mean_rstd ? mean_rstd[0] : 0.f;
+  const float rstd = mean_rstd ? mean_rstd[1] : 1.f;
+  const int expo = job_expo ? job_expo[job] : (mask ? 1 : 0);
+  const float* base = src + job_off[job];
+  for (int r = 0; r < RG; ++r) {
+    const int y = g.y0 + grp * RG + r;
+    const float* row = base + (int64_t)y * row_stride;
+    const float* mrow = mask + (int64_t)y * g.W;
+    auto load = [&](int j) {
+      const int x = 2 * j;
+      cfloat v = cmake(0.f, 0.f);
+      if (x >= g.x0 && x < g.x1) {
+        v = cmake((row[x] - mean) * rstd, (row[x + 1] - mean) * rstd);
+        if (expo > 0) {
+          const float m0 = mrow[x], m1 = mrow[x + 1];
+          for (int e = 0; e < expo; ++e) {
+            v.x *= m0;
+            v.y *= m1;
+          }
+        }
+      }
+      return v;
+    };
+    auto store = [&](int k, cfloat v) {
+      if (k < g.nkx) zlo[k] = v;
+      if (k > 0 && n - k <= g.nkx) zhi[n - k] = v;
+    };
+    wg_bluestein<M>(line, tid, ln.tw_m, ln.chirp, ln.bspec, n, load, store);
+    __syncthreads();
+    for (int k = tid; k < g.nkx; k += MC_WG) {
+      const cfloat zk = (k < n) ? zlo[k] : zlo[0];                  // Z[n] == Z[0]
+      const cfloat zm = cconj((k == 0 || k == n) ? zlo[0] : zhi[k]);  // Z[n-k]
+      const cfloat sm = cadd(zk, zm), d = csub(zk, zm);
+      const cfloat w = (k < n) ? tw_row[k] : cmake(-1.f, 0.f);
+      const cfloat wd = cmul(w, d);
+      stg[k * (RG + 1) + r] = cmake(0.5f * (sm.x + wd.y), 0.5f * (sm.y - wd.x));
+    }
+    __syncthreads();
+  }
+  cfloat* out = T1 + (int64_t)job * g.nkx * g.ny + (int64_t)grp * RG;
+  for (int i = tid; i < g.nkx * RG; i += MC_WG) {
+    const int kx = i / RG, r = i - kx * RG;
+    out[(int64_t)kx * g.ny + r] = stg[kx * (RG + 1) + r];
+  }
+}
+
+__device__ __forceinline__ int kept_index(int ky, int H, int kyp, int kyn) {
+  if (ky < kyp) return ky;
+  if (ky >= H - kyn) return ky - (H - kyn) + kyp;
+  return -1;
+}
+
+template <int LOGM>
+__global__ __launch_bounds__(MC_WG) void xcg_cols_fwd(const cfloat* __restrict__ T1,
+                                                      const float* __restrict__ filt,
+                                                      cfloat* __restrict__ S, XcLine ln, XcGeom g) {
+  constexpr int M = 1 << LOGM;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cfloat* line = reinterpret_cast<cfloat*>(smem);
+  const int tid = threadIdx.x;
+  const int kx = blockIdx.x, job = blockIdx.y;
+  const int H = g.H, nky = g.kyp + g.kyn;
+  const cfloat* col = T1 + ((int64_t)job * g.nkx + kx) * g.ny;
+  cfloat* out = S + ((int64_t)job * g.nkx + kx) * nky;
+  const float* f = filt ? filt + (int64_t)kx * nky : nullptr;
+  auto load = [&](int y) {
+    const int yy = y - g.y0;
+    return (yy >= 0 && yy < g.ny) ? col[yy] : cmake(0.f, 0.f);
+  };
+  auto store = [&](int ky, cfloat v) {
+    const int kyi = kept_index(ky, H, g.kyp, g.kyn);
+    if (kyi >= 0) out[kyi] = f ? cscale(v, f[kyi]) : v;
+  };
+  wg_bluestein<M>(line, tid, ln.tw_m, ln.chirp, ln.bspec, H, load, store);
+}
+
+// MODE 0: conj(ref)*cur; MODE 1: cur * exp(-2 pi i (fy sy + fx sx)) (Fourier shift)
+template <int LOGM, int MODE>
+__global__ __launch_bounds__(MC_WG) void xcg_cols_inv(
+    const cfloat* __restrict__ S_cur, const int* __restrict__ cur_idx,
+    const cfloat* __restrict__ S_ref, const int* __restrict__ ref_idx,
+    const float* __restrict__ shifts, cfloat* __restrict__ T2, float scale, XcLine ln, XcGeom g) {
+  constexpr int M = 1 << LOGM;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cfloat* line = reinterpret_cast<cfloat*>(smem);
+  const int tid = threadIdx.x;
+  const int kx = blockIdx.x, p = blockIdx.y;
+  const int H = g.H, nky = g.kyp + g.kyn;
+  const cfloat* cur = S_cur + ((int64_t)cur_idx[p] * g.nkx + kx) * nky;
+  const cfloat* ref = MODE == 0 ? S_ref + ((int64_t)ref_idx[p] * g.nkx + kx) * nky : nullptr;
+  cfloat* out = T2 + ((int64_t)p * g.nkx + kx) * H;
+  float sy = 0.f, sx = 0.f, fx = 0.f;
+  if (MODE == 1) {
+    sy = shifts[2 * p];
+    sx = shifts[2 * p + 1];
+    fx = (float)kx * (float)(1.0 / (double)g.W);  // torch.fft.rfftfreq: k * (1/n)
+  }
+  auto load = [&](int ky) {
+    const int kyi = kept_index(ky, H, g.kyp, g.kyn);
+    if (kyi < 0) return cmake(0.f, 0.f);
+    cfloat v;
+    if (MODE == 0) {
+      v = cmulc(ref[kyi], cur[kyi]);
+    } else {
+      const int kk = (ky < (H + 1) / 2) ? ky : ky - H;
+      const float fy = (float)kk * (float)(1.0 / (double)H);
+      const float m2pi = -6.283185307179586f;
+      const float ang = (m2pi * fy) * sy + (m2pi * fx) * sx;
+      float sn, cs;
+      sincosf(ang, &sn, &cs);
+      v = cmul(cur[kyi], cmake(cs, sn));
+    }
+    return cscale(v, scale);
+  };
+  auto store = [&](int y, cfloat v) { out[y] = v; };
+  wg_bluestein<M>(line, tid, ln.tw_m, ln.chirp, ln.bspec, H, load, store);
+}
+
+template <int LOGM, int EPI>
+__global__ __launch_bounds__(MC_WG) void xcg_rows_inv(
+    const cfloat* __restrict__ T2, const float* __restrict__ bounds, int* __restrict__ best,
+    float* __restrict__ part_val, int* __restrict__ part_idx, float* __restrict__ out_real,
+    const int64_t* __restrict__ out_off, int64_t out_stride, const cfloat* __restrict__ tw_row,
+    XcLine ln, XcGeom g, int near, int phase) {
+  constexpr int M = 1 << LOGM;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cfloat* line = reinterpret_cast<cfloat*>(smem);
+  cfloat* stg = line + lds_len(M);
+  const int tid = threadIdx.x;
+  const int p = blockIdx.y;
+  const int RG = g.RG, n = ln.n;
+  const int ngrp = g.H / RG;
+  int grp = blockIdx.x;
+  if (EPI == 0) grp = phase == 0 ? ((int)blockIdx.x < near ? (int)blockIdx.x : ngrp - 2 * near + (int)blockIdx.x)
+                                 : near + (int)blockIdx.x;
+  if constexpr (EPI == 0) {
+    if (phase == 1) {
+      float b = 0.f;
+      for (int r = 0; r < RG; ++r) b = fmaxf(b, bounds[(int64_t)p * g.H + grp * RG + r]);
+      b = b * 1.0001f + 1e-30f;
+      if (float_order(b) < __hip_atomic_load(&best[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        if (tid == 0) {
+          part_val[(int64_t)p * ngrp + grp] = -INFINITY;
+          part_idx[(int64_t)p * ngrp + grp] = 0x7fffffff;
+        }
+        return;
+      }
+    }
+  }
+  const cfloat* in = T2 + (int64_t)p * g.nkx * g.H + (int64_t)grp * RG;
+  for (int i = tid; i < g.nkx * RG; i += MC_WG) {
+    const int kx = i / RG, r = i - kx * RG;
+    stg[kx * (RG + 1) + r] = in[(int64_t)kx * g.H + r];
+  }
+  __syncthreads();
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int r = 0; r < RG; ++r) {
+    const int y = grp * RG + r;
+    // c2r pack for a real row of even length W = 2n (same identity as the 2^k path)
+    auto load = [&](int k) {
+      const int km = n - k;  // in [1, n]
+      cfloat xk = (k < g.nkx) ? stg[k * (RG + 1) + r] : cmake(0.f, 0.f);
+      cfloat xm = (km < g.nkx) ? cconj(stg[km * (RG + 1) + r]) : cmake(0.f, 0.f);
+      if (k == 0) {
+        xk.y = 0.f;
+        xm.y = 0.f;
+      }
+      const cfloat sm = cadd(xk, xm), d = csub(xk, xm);
+      cfloat w = tw_row[k];
+      w.y = -w.y;
+      const cfloat wd = cmul(w, d);
+      return cmake(sm.x - wd.y, sm.y + wd.x);
+    };
+    if constexpr (EPI == 0) {
+      auto store = [&](int j, cfloat v) {
+        const int flat = y * g.W + 2 * j;
+        cand_merge(bv, bi, v.x, flat);
+        cand_merge(bv, bi, v.y, flat + 1);
+      };
+      wg_bluestein<M>(line, tid, ln.tw_m, ln.chirp, ln.bspec, n, load, store);
+    } else {
+      float* orow = out_real + out_off[p] + (int64_t)y * out_stride;
+      auto store = [&](int j, cfloat v) {
+        orow[2 * j] = v.x;
+        orow[2 * j + 1] = v.y;
+      };
+      wg_bluestein<M>(line, tid, ln.tw_m, ln.chirp, ln.bspec, n, load, store);
+    }
+    __syncthreads();
+  }
+  if constexpr (EPI == 0) {
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_down(bv, off);
+      const int oi = __shfl_down(bi, off);
+      cand_merge(bv, bi, ov, oi);
+    }
+    __shared__ float wv[MC_WG / 64];
+    __shared__ int wi[MC_WG / 64];
+    if ((tid & 63) == 0) {
+      wv[tid >> 6] = bv;
+      wi[tid >> 6] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < MC_WG / 64; ++w) cand_merge(bv, bi, wv[w], wi[w]);
+      part_val[(int64_t)p * ngrp + grp] = bv;
+      part_idx[(int64_t)p * ngrp + grp] = bi;
+      atomicMax(&best[p], float_order(bv));
+    }
+  }
+}
+
+#define MC_DISPATCH_LOGM(LOGV, ...)          \
+  switch (LOGV) {                            \
+    MC_DISPATCH_CASE(5, __VA_ARGS__)         \
+    MC_DISPATCH_CASE(6, __VA_ARGS__)         \
+    MC_DISPATCH_CASE(7, __VA_ARGS__)         \
+    MC_DISPATCH_CASE(8, __VA_ARGS__)         \
+    MC_DISPATCH_CASE(9, __VA_ARGS__)         \
+    MC_DISPATCH_CASE(10, __VA_ARGS__)        \
+    MC_DISPATCH_CASE(11, __VA_ARGS__)        \
+    MC_DISPATCH_CASE(12, __VA_ARGS__)        \
+    MC_DISPATCH_CASE(13, __VA_ARGS__)        \
+    default:                                 \
+      return MC_ERR_UNSUPPORTED;             \
+  }
+
+// geometry check without the power-of-two requirement
+static int geom_from_g(const mc_xc_geom* q, XcGeom* g) {
+  if (!q) return MC_ERR_ARG;
+  if (q->W < 4 || (q->W & 1) || q->W > 8192 || q->H < 2 || q->H > 4096) return MC_ERR_UNSUPPORTED;
+  if (q->nkx < 1 || q->nkx > q->W / 2 + 1) return MC_ERR_ARG;
+  if (q->kyp < 0 || q->kyn < 0 || q->kyp + q->kyn < 1 || q->kyp + q->kyn > q->H) return MC_ERR_ARG;
+  if (q->RG < 1 || q->ny < 1 || q->ny % q->RG || q->H % q->RG) return MC_ERR_ARG;
+  if (q->y0 < 0 || q->y0 + q->ny > q->H) return MC_ERR_ARG;
+  if (q->x0 < 0 || q->x1 > q->W || (q->x0 & 1) || (q->x1 & 1) || q->x0 >= q->x1) return MC_ERR_ARG;
+  g->W = q->W; g->H = q->H; g->nkx = q->nkx; g->kyp = q->kyp; g->kyn = q->kyn;
+  g->y0 = q->y0; g->ny = q->ny; g->x0 = q->x0; g->x1 = q->x1; g->RG = q->RG;
+  return MC_OK;
+}
+
+static int line_from(const mc_xc_line* l, int n, XcLine* out, int* logm) {
+  if (!l || !l->tw_m || !l->chirp || !l->bspec) return MC_ERR_ARG;
+  if (!mc_is_pow2(l->M) || l->M < 32 || l->M > 8192 || l->M < 2 * n - 1) return MC_ERR_UNSUPPORTED;
+  out->tw_m = (const cfloat*)l->tw_m; out->chirp = (const cfloat*)l->chirp;
+  out->bspec = (const cfloat*)l->bspec; out->n = n;
+  *logm = mc_ilog2(l->M);
+  return MC_OK;
+}
+
+#define MC_SET_LDS(k, bytes) \
+  (void)hipFuncSetAttribute((const void*)(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))
+
+extern "C" {
+
+int mc_xcg_rows_forward(const float* src, const int64_t* job_off, int64_t row_stride,
+                        const int* job_expo, const float* mask, const float* mean_rstd, void* T1,
+                        const void* tw_row, const mc_xc_line* line, int njobs, const mc_xc_geom* q,
+                        void* stream) {
+  XcGeom g; XcLine ln; int logm;
+  int rc = geom_from_g(q, &g);
+  if (rc) return rc;
+  if ((rc = line_from(line, g.W / 2, &ln, &logm))) return rc;
+  if (!src || !job_off || !T1 || !tw_row || njobs < 1) return MC_ERR_ARG;
+  const size_t lds = sizeof(cfloat) * ((size_t)lds_len(line->M) + 2 * (g.nkx + 1) + (size_t)g.nkx * (g.RG + 1));
+  if (lds > 160 * 1024) return MC_ERR_ARG;
+  dim3 grid(njobs, g.ny / g.RG);
+  MC_DISPATCH_LOGM(logm, {
+    auto k = xcg_rows_fwd<L>;
+    MC_SET_LDS(k, lds);
+    hipLaunchKernelGGL(k, grid, dim3(MC_WG), lds, (hipStream_t)stream, src, job_off, row_stride,
+                       job_expo, mask, mean_rstd, (cfloat*)T1, (const cfloat*)tw_row, ln, g);
+  });
+  return mc_check_launch();
+}
+
+int mc_xcg_cols_forward(const void* T1, const float* filt, void* S, const mc_xc_line* line,
+                        int njobs, const mc_xc_geom* q, void* stream) {
+  XcGeom g; XcLine ln; int logm;
+  int rc = geom_from_g(q, &g);
+  if (rc) return rc;
+  if ((rc = line_from(line, g.H, &ln, &logm))) return rc;
+  if (!T1 || !S || njobs < 1) return MC_ERR_ARG;
+  const size_t lds = sizeof(cfloat) * (size_t)lds_len(line->M);
+  dim3 grid(g.nkx, njobs);
+  MC_DISPATCH_LOGM(logm, {
+    auto k = xcg_cols_fwd<L>;
+    MC_SET_LDS(k, lds);
+    hipLaunchKernelGGL(k, grid, dim3(MC_WG), lds, (hipStream_t)stream, (const cfloat*)T1, filt,
+                       (cfloat*)S, ln, g);
+  });
+  return mc_check_launch();
+}
+
+int mc_xcg_cols_inverse(const void* S_cur, const int* cur_idx, const void* S_ref,
+                        const int* ref_idx, const float* shifts, void* T2, const mc_xc_line* line,
+                        float scale, int npairs, const mc_xc_geom* q, void* stream) {
+  XcGeom g; XcLine ln; int logm;
+  int rc = geom_from_g(q, &g);
+  if (rc) return rc;
+  if ((rc = line_from(line, g.H, &ln, &logm))) return rc;
+  if (!S_cur || !cur_idx || !T2 || npairs < 1 || (!shifts && (!S_ref || !ref_idx))) return MC_ERR_ARG;
+  const size_t lds = sizeof(cfloat) * (size_t)lds_len(line->M);
+  dim3 grid(g.nkx, npairs);
+  MC_DISPATCH_LOGM(logm, {
+    if (shifts) {
+      auto k = xcg_cols_inv<L, 1>;
+      MC_SET_LDS(k, lds);
+      hipLaunchKernelGGL(k, grid, dim3(MC_WG), lds, (hipStream_t)stream, (const cfloat*)S_cur, cur_idx,
+                         (const cfloat*)nullptr, (const int*)nullptr, shifts, (cfloat*)T2, scale, ln, g);
+    } else {
+      auto k = xcg_cols_inv<L, 0>;
+      MC_SET_LDS(k, lds);
+      hipLaunchKernelGGL(k, grid, dim3(MC_WG), lds, (hipStream_t)stream, (const cfloat*)S_cur, cur_idx,
+                         (const cfloat*)S_ref, ref_idx, (const float*)nullptr, (cfloat*)T2, scale, ln, g);
+    }
+  });
+  return mc_check_launch();
+}
+
+int mc_xcg_rows_inverse(const void* T2, float* part_val, int* part_idx, int* peaks, float* shifts,
+                        float* out, const int64_t* out_off, int64_t out_stride, const void* tw_row,
+                        const mc_xc_line* line, int npairs, const mc_xc_geom* q, void* stream) {
+  XcGeom g; XcLine ln; int logm;
+  int rc = geom_from_g(q, &g);
+  if (rc) return rc;
+  if ((rc = line_from(line, g.W / 2, &ln, &logm))) return rc;
+  if (!T2 || !tw_row || npairs < 1) return MC_ERR_ARG;
+  const bool store = out != nullptr;
+  if (store ? !out_off : (!part_val || !part_idx || !peaks || !shifts)) return MC_ERR_ARG;
+  const size_t lds = sizeof(cfloat) * ((size_t)lds_len(line->M) + (size_t)g.nkx * (g.RG + 1));
+  if (lds > 160 * 1024) return MC_ERR_ARG;
+  const int ngrp = g.H / g.RG;
+  if (store) {
+    MC_DISPATCH_LOGM(logm, {
+      auto k = xcg_rows_inv<L, 1>;
+      MC_SET_LDS(k, lds);
+      hipLaunchKernelGGL(k, dim3(ngrp, npairs), dim3(MC_WG), lds, (hipStream_t)stream, (const cfloat*)T2,
+                         (const float*)nullptr, (int*)nullptr, (float*)nullptr, (int*)nullptr, out, out_off,
+                         out_stride, (const cfloat*)tw_row, ln, g, 0, 0);
+    });
+    return mc_check_launch();
+  }
+  int* best = part_idx + (int64_t)npairs * ngrp;
+  {
+    const float ninf = -INFINITY;
+    int pat;
+    memcpy(&pat, &ninf, 4);
+    pat = pat >= 0 ? pat : pat ^ 0x7fffffff;
+    hipError_t e = hipMemsetD32Async((hipDeviceptr_t)best, pat, npairs, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  int near = (64 + g.RG - 1) / g.RG;
+  if (2 * near > ngrp) near = ngrp / 2;
+  float* bounds = part_val + (int64_t)npairs * ngrp;
+  if (ngrp - 2 * near > 0)
+    hipLaunchKernelGGL(xc_row_bounds, dim3((g.H + 63) / 64, npairs), dim3(256), 0, (hipStream_t)stream,
+                       (const cfloat*)T2, bounds, g.nkx, g.H);
+  MC_DISPATCH_LOGM(logm, {
+    auto k = xcg_rows_inv<L, 0>;
+    MC_SET_LDS(k, lds);
+    if (near > 0)
+      hipLaunchKernelGGL(k, dim3(2 * near, npairs), dim3(MC_WG), lds, (hipStream_t)stream, (const cfloat*)T2,
+                         (const float*)bounds, best, part_val, part_idx, (float*)nullptr,
+                         (const int64_t*)nullptr, (int64_t)0, (const cfloat*)tw_row, ln, g, near, 0);
+    if (ngrp - 2 * near > 0)
+      hipLaunchKernelGGL(k, dim3(ngrp - 2 * near, npairs), dim3(MC_WG), lds, (hipStream_t)stream,
+                         (const cfloat*)T2, (const float*)bounds, best, part_val, part_idx, (float*)nullptr,
+                         (const int64_t*)nullptr, (int64_t)0, (const cfloat*)tw_row, ln, g, near, 1);
+  });
+  rc = mc_check_launch();
+  if (rc) return rc;
+  hipLaunchKernelGGL(xc_peak_final, dim3(npairs), dim3(64), 0, (hipStream_t)stream, part_val, part_idx,
+                     ngrp, g.H, g.W, peaks, shifts);
   return mc_check_launch();
 }
 

@@ -64,6 +64,26 @@ def normalize(img: torch.Tensor, stats: torch.Tensor) -> torch.Tensor:
 # ------------------------------------------------------------------ spectra
 
 
+def _pow2(n: int) -> bool:
+    return n > 0 and (n & (n - 1)) == 0
+
+
+def _k1(lib, g, dev, src, off, row_stride, expo, mask, stats, T1, tw_row, n, st):
+    if _pow2(g.W):
+        return lib.mc_xc_rows_forward(ptr(src), ptr(off), row_stride, ptr(expo), ptr(mask), ptr(stats),
+                                      ptr(T1), ptr(tw_row), n, g, st)
+    line, _ = planmod.line_plan(g.W // 2, -1, dev)
+    return lib.mc_xcg_rows_forward(ptr(src), ptr(off), row_stride, ptr(expo), ptr(mask), ptr(stats),
+                                   ptr(T1), ptr(tw_row), line, n, g, st)
+
+
+def _k2(lib, g, dev, T1, filt, S, tw_col, n, st):
+    if _pow2(g.H):
+        return lib.mc_xc_cols_forward(ptr(T1), ptr(filt), ptr(S), ptr(tw_col), n, g, st)
+    line, _ = planmod.line_plan(g.H, -1, dev)
+    return lib.mc_xcg_cols_forward(ptr(T1), ptr(filt), ptr(S), line, n, g, st)
+
+
 def _forward_spectra(src, job_off, row_stride, job_expo, pl, stats, use_mask=True, use_filter=True):
     """K1+K2 for a list of jobs -> S (njobs, nkx, nky, 2)."""
     lib = _lib.load()
@@ -78,11 +98,10 @@ def _forward_spectra(src, job_off, row_stride, job_expo, pl, stats, use_mask=Tru
         n = min(chunk, njobs - a)
         off = job_off[a : a + n]
         expo = None if job_expo is None else job_expo[a : a + n]
-        check(lib.mc_xc_rows_forward(ptr(src), ptr(off), row_stride, ptr(expo),
-                                     ptr(pl.mask) if use_mask else None, ptr(stats), ptr(T1),
-                                     ptr(pl.tw_row), n, g, st), "mc_xc_rows_forward")
-        check(lib.mc_xc_cols_forward(ptr(T1), ptr(pl.filt) if use_filter else None, ptr(S[a : a + n]),
-                                     ptr(pl.tw_col), n, g, st), "mc_xc_cols_forward")
+        check(_k1(lib, g, dev, src, off, row_stride, expo, pl.mask if use_mask else None, stats, T1,
+                  pl.tw_row, n, st), "xc rows forward")
+        check(_k2(lib, g, dev, T1, pl.filt if use_filter else None, S[a : a + n], pl.tw_col, n, st),
+              "xc cols forward")
     return S
 
 
@@ -104,13 +123,27 @@ def _peaks(S_cur, cur_idx, S_ref, ref_idx, pl, want_nbhd):
     scale = 1.0 / (g.H * g.W)
     for a in range(0, npairs, chunk):
         n = min(chunk, npairs - a)
-        check(lib.mc_xc_cols_inverse(ptr(S_cur), ptr(cur_idx[a : a + n]), ptr(S_ref),
-                                     ptr(ref_idx[a : a + n]), ptr(T2), ptr(pl.tw_col), scale, n, g,
-                                     st), "mc_xc_cols_inverse")
-        check(lib.mc_xc_rows_inverse_argmax(ptr(T2), ptr(pv), ptr(pi), ptr(peaks[a : a + n]),
-                                            ptr(shifts[a : a + n]), ptr(pl.tw_row), n, g, st),
-              "mc_xc_rows_inverse_argmax")
+        if _pow2(g.H):
+            check(lib.mc_xc_cols_inverse(ptr(S_cur), ptr(cur_idx[a : a + n]), ptr(S_ref),
+                                         ptr(ref_idx[a : a + n]), ptr(T2), ptr(pl.tw_col), scale, n, g,
+                                         st), "mc_xc_cols_inverse")
+        else:
+            line, _ = planmod.line_plan(g.H, +1, dev)
+            check(lib.mc_xcg_cols_inverse(ptr(S_cur), ptr(cur_idx[a : a + n]), ptr(S_ref),
+                                          ptr(ref_idx[a : a + n]), None, ptr(T2), line, scale, n, g, st),
+                  "mc_xcg_cols_inverse")
+        if _pow2(g.W):
+            check(lib.mc_xc_rows_inverse_argmax(ptr(T2), ptr(pv), ptr(pi), ptr(peaks[a : a + n]),
+                                                ptr(shifts[a : a + n]), ptr(pl.tw_row), n, g, st),
+                  "mc_xc_rows_inverse_argmax")
+        else:
+            line, _ = planmod.line_plan(g.W // 2, +1, dev)
+            check(lib.mc_xcg_rows_inverse(ptr(T2), ptr(pv), ptr(pi), ptr(peaks[a : a + n]),
+                                          ptr(shifts[a : a + n]), None, None, 0, ptr(pl.tw_row), line, n,
+                                          g, st), "mc_xcg_rows_inverse")
         if want_nbhd:
+            if not _pow2(g.W):
+                raise NotImplementedError("sub-pixel neighbourhood needs a power-of-two patch size")
             check(lib.mc_xc_peak_neighbourhood(ptr(T2), ptr(peaks[a : a + n]), ptr(nb[a : a + n]),
                                                ptr(pl.tw_row), n, g, st),
                   "mc_xc_peak_neighbourhood")
@@ -141,8 +174,8 @@ def _global_spectra(img, pl):
     hl, hu, wl, wu = int(0.25 * h), int(0.75 * h), int(0.25 * w), int(0.75 * w)
     job_off = _cached(("frame_off", str(dev), t, h, w),
                       lambda: torch.arange(t, device=dev, dtype=torch.int64) * (h * w))
-    fused = (hl >= g.y0 and hu <= g.y0 + g.ny and wl >= g.x0 and wu <= g.x1 and wl % 2 == 0
-             and wu % 2 == 0 and hu > hl and wu > wl)
+    fused = (_pow2(g.W) and _pow2(g.H) and hl >= g.y0 and hu <= g.y0 + g.ny and wl >= g.x0
+             and wu <= g.x1 and wl % 2 == 0 and wu % 2 == 0 and hu > hl and wu > wl)
     if not fused:
         return _forward_spectra(img, job_off, w, None, pl, central_box_stats(img))
     st = stream_ptr(dev)
@@ -364,16 +397,24 @@ def fourier_shift(img, shifts):
     for a in range(0, t, chunk):
         n = min(chunk, t - a)
         off = torch.arange(a, a + n, device=dev, dtype=torch.int64) * (h * w)
-        check(lib.mc_xc_rows_forward(ptr(img), ptr(off), w, None, None, None, ptr(T1), ptr(tw_row), n,
-                                     g, st), "mc_xc_rows_forward")
-        check(lib.mc_xc_cols_forward(ptr(T1), None, ptr(S), ptr(tw_col), n, g, st),
-              "mc_xc_cols_forward")
+        check(_k1(lib, g, dev, img, off, w, None, None, None, T1, tw_row, n, st), "xc rows forward")
+        check(_k2(lib, g, dev, T1, None, S, tw_col, n, st), "xc cols forward")
         # T1 is dead now and has the same footprint as T2: reuse it
-        check(lib.mc_fourier_shift_cols_inverse(ptr(S), ptr(idx), ptr(shifts[a : a + n]), ptr(T1),
-                                                ptr(tw_col), 1.0 / (h * w), n, g, st),
-              "mc_fourier_shift_cols_inverse")
-        check(lib.mc_xc_rows_inverse_store(ptr(T1), ptr(out), ptr(off), w, ptr(tw_row), n, g, st),
-              "mc_xc_rows_inverse_store")
+        if _pow2(g.H):
+            check(lib.mc_fourier_shift_cols_inverse(ptr(S), ptr(idx), ptr(shifts[a : a + n]), ptr(T1),
+                                                    ptr(tw_col), 1.0 / (h * w), n, g, st),
+                  "mc_fourier_shift_cols_inverse")
+        else:
+            line, _ = planmod.line_plan(g.H, +1, dev)
+            check(lib.mc_xcg_cols_inverse(ptr(S), ptr(idx), None, None, ptr(shifts[a : a + n]), ptr(T1),
+                                          line, 1.0 / (h * w), n, g, st), "mc_xcg_cols_inverse")
+        if _pow2(g.W):
+            check(lib.mc_xc_rows_inverse_store(ptr(T1), ptr(out), ptr(off), w, ptr(tw_row), n, g, st),
+                  "mc_xc_rows_inverse_store")
+        else:
+            line, _ = planmod.line_plan(g.W // 2, +1, dev)
+            check(lib.mc_xcg_rows_inverse(ptr(T1), None, None, None, None, ptr(out), ptr(off), w,
+                                          ptr(tw_row), line, n, g, st), "mc_xcg_rows_inverse")
     return out
 
 

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import XcGeom, check, ptr, stream_ptr
+from ._lib import XcGeom, XcLine, check, ptr, stream_ptr
 
 LDS_BUDGET = 80 * 1024  # bytes per workgroup for the row kernels (2 workgroups / CU)
 
@@ -38,10 +38,11 @@ def xc_geometry(h: int, w: int, high: float, radius: float, smoothing: float) ->
     """Pruning bounds for an (h, w) transform: which rfft columns / fft rows can be
     non-zero under the band-pass `f <= high`, and which window rows/columns can be
     non-zero under the soft disk mask.  All bounds are conservative supersets."""
-    if not (_is_pow2(h) and _is_pow2(w) and 32 <= w <= 8192 and 16 <= h <= 4096):
+    if not (4 <= w <= 8192 and w % 2 == 0 and 2 <= h <= 4096) or (_is_pow2(w) and w < 32) or (
+            _is_pow2(h) and h < 16):
         raise NotImplementedError(
-            f"transform size {h}x{w}: this build of libmcorr has power-of-two FFT lengths only "
-            "(32<=w<=8192, 16<=h<=4096)"
+            f"transform size {h}x{w}: libmcorr handles even widths up to 8192 and heights up to 4096 "
+            "(power-of-two lengths natively, other lengths by chirp-z)"
         )
     hi32 = np.float32(high)
     fx = np.arange(w // 2 + 1, dtype=np.float32) * np.float32(1.0 / w)
@@ -65,12 +66,22 @@ def xc_geometry(h: int, w: int, high: float, radius: float, smoothing: float) ->
     x0 -= x0 & 1
     x1 += x1 & 1
     n_line = w // 2
-    subgroups = 256 // min(256, max(64, n_line // 8))  # rows transformed side by side (mc_fft.h)
-    lines = subgroups * 2 * (n_line + (n_line >> 4) + 1)
-    rg = 16
-    while rg > subgroups and 8 * (lines + nkx * (rg + 1)) > LDS_BUDGET:
+    if _is_pow2(w):
+        subgroups = 256 // min(256, max(64, n_line // 8))  # rows transformed side by side (mc_fft.h)
+        lines = subgroups * 2 * (n_line + (n_line >> 4) + 1)
+        rg = 16
+    else:  # chirp-z rows: one line of M = pow2 >= 2*(w/2)-1 points + two small side buffers
+        subgroups = 1
+        m = bluestein_size(n_line)
+        lines = (m + (m >> 4) + 1) + 2 * (nkx + 1)
+        rg = 4
+    while rg > subgroups and 8 * (lines + nkx * (rg + 1)) > (LDS_BUDGET if _is_pow2(w) else 150 * 1024):
+        rg //= 2
+    while rg > 1 and h % rg:
         rg //= 2
     rg = min(rg, h)
+    if rg < subgroups or h % rg:
+        raise NotImplementedError(f"transform size {h}x{w}: no valid row grouping")
     y0 -= y0 % rg
     y1 = min(h, ((y1 + rg - 1) // rg) * rg)
     return XcGeom(W=w, H=h, nkx=nkx, kyp=kyp, kyn=kyn, y0=y0, ny=y1 - y0, x0=x0, x1=x1, RG=rg)
@@ -79,6 +90,42 @@ def xc_geometry(h: int, w: int, high: float, radius: float, smoothing: float) ->
 def full_geometry(h: int, w: int) -> XcGeom:
     """No pruning at all (correct_motion_fast needs the full spectrum)."""
     return xc_geometry(h, w, high=10.0, radius=float(max(h, w)), smoothing=0.0)
+
+
+def bluestein_size(n: int) -> int:
+    m = 32
+    while m < 2 * n - 1:
+        m *= 2
+    return m
+
+
+_LINES: dict = {}
+
+
+def line_plan(n: int, direction: int, device):
+    """Chirp-z tables for a length-n transform (any n), direction -1 forward / +1 inverse:
+    chirp[j] = exp(direction * i*pi*j^2/n) with j^2 reduced mod 2n in integers, bspec =
+    FFT_M(wrapped conj(chirp)) / M.  Returns (XcLine, keep-alive tensors)."""
+    key = (str(device), n, direction)
+    if key in _LINES:
+        return _LINES[key]
+    m = bluestein_size(n)
+    if m > 8192:
+        raise NotImplementedError(f"transform length {n}: chirp-z needs M={m} > 8192")
+    j = np.arange(n, dtype=np.int64)
+    ang = direction * np.pi * ((j * j) % (2 * n)).astype(np.float64) / n
+    chirp = np.exp(1j * ang)
+    b = np.conj(chirp)
+    bw = np.zeros(m, dtype=np.complex128)
+    bw[:n] = b
+    if n > 1:
+        bw[m - n + 1:] = b[1:][::-1]
+    bspec = np.fft.fft(bw) / m
+    to_dev = lambda z: torch.from_numpy(np.stack([z.real, z.imag], -1).astype(np.float32)).to(device)
+    tw_m, ch, bs = get_twiddles(m, device), to_dev(chirp), to_dev(bspec)
+    line = XcLine(tw_m=tw_m.data_ptr(), chirp=ch.data_ptr(), bspec=bs.data_ptr(), M=m)
+    _LINES[key] = (line, (tw_m, ch, bs))
+    return _LINES[key]
 
 
 def twiddles(n: int, device) -> torch.Tensor:
@@ -144,3 +191,4 @@ def get_xc_plan(h: int, w: int, pixel_spacing: float, b_factor: float, frequency
 def clear_plan_cache():
     _PLANS.clear()
     _TWIDDLES.clear()
+    _LINES.clear()
