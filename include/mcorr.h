@@ -71,12 +71,18 @@ int mc_xc_rows_forward(const float* src, const int64_t* job_off, int64_t row_str
                        const int* job_expo, const float* mask, const float* mean_rstd, void* T1,
                        const void* tw_row, int njobs, const mc_xc_geom* geom, void* stream);
 
+/* Row-transform engine of K1: 0 = automatic (W == 4096, nkx <= 512, no per-job exponents,
+ * 16-byte aligned src/mask and row_stride % 4 == 0 -> one wavefront per row, mc_wave_fft.h;
+ * job_off[] must then be multiples of 4 floats, as whole-frame offsets f*h*w are),
+ * 1 = always one workgroup per row.  Process-wide; results agree to fp32 rounding. */
+int mc_xc_row_engine(int mode);
+
 /* K1 with the normalisation statistics fused in (whole-frame jobs only): samples become
  * (x - m0[0]) * mask (m0: device float[3] = {provisional mean, 1, 1}); while reading, the
  * sums of (x-m0) and (x-m0)^2 over the central box rows [hl,hu) x cols [wl,wu) (window
  * coordinates, inside the mask support, wl/wu even) of every job are accumulated;
  * afterwards fix = {mean - m0, 1/std} and out3 = {mean, 1/std, std} (unbiased std over
- * all jobs jointly, utils.py:76-84).  acc: 2 doubles scratch.  Feed `fix` to
+ * all jobs jointly, utils.py:76-84).  acc: 128 doubles scratch (64 x {sum, sumsq}).  Feed `fix` to
  * mc_xc_cols_forward_fix, which finishes the normalisation by linearity. */
 int mc_xc_rows_forward_stats(const float* src, const int64_t* job_off, int64_t row_stride,
                              const float* mask, const float* m0, void* T1, const void* tw_row,

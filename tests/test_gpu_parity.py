@@ -523,3 +523,56 @@ def test_correct_motion_fast_on_arbitrary_sizes(mc, dev, shape):
 def test_odd_width_is_rejected_loudly(mc, dev):
     with pytest.raises(NotImplementedError, match="even widths"):
         mc.estimate_global_motion(torch.randn(3, 64, 65, device=dev), 1.0)
+
+
+# ------------------------------------------------------------------ wave-per-row K1
+
+
+@pytest.mark.parametrize("h", [4096, 512])
+def test_wave_row_engine_matches_workgroup_engine(dev, h):
+    """The wavefront-per-row K1 (mc_wave_fft.h; W = 4096, nkx <= 512) against the
+    workgroup-per-row K1 on the same frames: T1, the fused box statistics, and the
+    final filtered spectra.  h = 512 puts the mask support inside chunks 7..8 of the row
+    (clamped sample loads + exact mask zeros), h = 4096 is the benchmark geometry."""
+    from torch_motion_correction_amd import _lib, engine, plan
+    from torch_motion_correction_amd._lib import check, ptr, stream_ptr
+
+    lib = _lib.load()
+    w, t = 4096, 2
+    g = torch.Generator().manual_seed(h)
+    img = (torch.randn(t, h, w, generator=g) * 1.7 + 11.0).to(dev)
+    pl = plan.get_xc_plan(h, w, 1.0, 500.0, (300, 10), dev)
+    gm = pl.geom
+    assert gm.nkx <= 512 and gm.ny % 8 == 0
+    off = torch.arange(t, device=dev, dtype=torch.int64) * (h * w)
+    hl, hu, wl, wu = int(0.25 * h), int(0.75 * h), int(0.25 * w), int(0.75 * w)
+    if h == 512:  # the statistics box must lie inside the region K1 reads
+        wl, wu = 1900, 2200
+    assert gm.x0 <= wl and wu <= gm.x1 and gm.y0 <= hl and hu <= gm.y0 + gm.ny
+    m0 = torch.tensor([11.0, 1.0, 1.0], device=dev)
+    res = {}
+    try:
+        for mode in (1, 0):
+            check(lib.mc_xc_row_engine(mode), "mc_xc_row_engine")
+            T1 = torch.zeros((t, gm.nkx, gm.ny, 2), device=dev)
+            acc = torch.empty(128, dtype=torch.float64, device=dev)
+            fix = torch.empty(2, device=dev)
+            out3 = torch.empty(3, device=dev)
+            check(lib.mc_xc_rows_forward_stats(ptr(img), ptr(off), w, ptr(pl.mask), ptr(m0), ptr(T1),
+                                               ptr(pl.tw_row), t, gm, hl, hu, wl, wu, ptr(acc), ptr(fix),
+                                               ptr(out3), stream_ptr(dev)), "rows_forward_stats")
+            plain = torch.zeros_like(T1)
+            st = torch.tensor([11.0, 0.5], device=dev)
+            check(lib.mc_xc_rows_forward(ptr(img), ptr(off), w, None, ptr(pl.mask), ptr(st), ptr(plain),
+                                         ptr(pl.tw_row), t, gm, stream_ptr(dev)), "rows_forward")
+            S = engine._global_spectra(img, pl)
+            res[mode] = [x.cpu() for x in (T1, out3, plain, S)]
+    finally:
+        lib.mc_xc_row_engine(0)
+    for a, b, tol in zip(res[0], res[1], (3e-6, 1e-6, 3e-6, 1e-5)):
+        assert torch.isfinite(a).all()
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max())
+    # statistics against torch on the central box
+    std, mean = torch.std_mean(img[:, hl:hu, wl:wu].double())
+    assert float(res[0][1][0]) == pytest.approx(float(mean), rel=1e-6)
+    assert float(res[0][1][2]) == pytest.approx(float(std), rel=1e-5)

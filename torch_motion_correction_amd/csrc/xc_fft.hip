@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "mc_fft.h"
+#include "mc_wave_fft.h"
 #include "mcorr.h"
 
 struct XcGeom {
@@ -159,11 +160,225 @@ __global__ __launch_bounds__(MC_WG) void xc_rows_fwd(
   }
 }
 
-// (sum, sumsq) of (x - m0) over `count` samples -> fix = {mean - m0, 1/std},
-// out3 = {mean, 1/std, std}  (unbiased std, as torch.std_mean, utils.py:81)
-__global__ void xc_stats_finalize(const double* __restrict__ acc, double count,
+// ------------------------------------------------------------------ K1, wave per row
+// W = 4096 rows (N = 2048 complex points) with nkx <= 512: one wavefront transforms one
+// row on its own (mc_wave_fft.h): no workgroup barrier anywhere in the row loop, 8 KiB of
+// LDS per wave, so 12-16 independent row streams per CU keep their HBM loads in flight.
+// A wave takes 4 consecutive rows (two pairs), a workgroup 16: bins of a row pair leave
+// as one 16-byte store per (kx, pair) and a workgroup completes whole 128-byte lines of
+// T1[job][kx][y].  Same arithmetic as xc_rows_fwd up to the summation order of the FFT.
+__device__ __forceinline__ void wf_sync() {
+  // wave-private LDS hand-off: DS operations of one wave execute in order, so this only
+  // has to stop the compiler from moving a lane's reads above other lanes' writes
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+#define XC_STAT_SLOTS 64  // stats_acc = XC_STAT_SLOTS x {sum, sumsq} doubles
+
+// N1LO / N1HI: the 256-sample chunks [N1LO, N1HI) of a row can touch the mask support;
+// the others are zero and are not loaded at all.
+template <int KEEP, bool STATS, int N1LO, int N1HI>
+__device__ __forceinline__ void wf_row(const float* __restrict__ row, const float* __restrict__ mrow,
+                                       int t, const WfLane& L, cfloat* slab, const XcGeom& g,
+                                       const XcBox& box, bool in_box_row, float mean, float rstd,
+                                       const cfloat* __restrict__ tw_row,
+                                       float& st_s, float& st_q, cfloat (&X)[4][KEEP]) {
+  cfloat A0[16], A1[16];
+  // Branch-free loads.  Samples: a lane whose quad lies outside the support [x0, x1) reads
+  // the nearest quad inside it instead (a line its neighbours fetch anyway: no extra HBM
+  // traffic) and is then multiplied by the mask's exact zero.  Mask rows (L2-resident):
+  // read as they are, in four groups behind the samples so that only one group of mask
+  // registers is live at a time.
+  const int xlo = g.x0 & ~3, xhi = ((g.x1 + 3) & ~3) - 4;
+  float4 px[16];
+#pragma unroll
+  for (int n1 = N1LO; n1 < N1HI; ++n1) {
+    const int x = 256 * n1 + 4 * t;
+    const int xs = x < xlo ? xlo : (x > xhi ? xhi : x);
+    px[n1] = *reinterpret_cast<const float4*>(row + xs);
+  }
+  // twiddles of pass A: W_2048^q = tw_row[2 q], q = 2 t, 2 t + 1 (L1-resident table)
+  const cfloat wA0 = tw_row[4 * t], wA1 = tw_row[4 * t + 2];
+#pragma unroll
+  for (int grp4 = 0; grp4 < 4; ++grp4) {
+    float4 mk[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n1 = 4 * grp4 + j;
+      if (n1 >= N1LO && n1 < N1HI) mk[j] = *reinterpret_cast<const float4*>(mrow + 256 * n1 + 4 * t);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n1 = 4 * grp4 + j;
+      if (n1 >= N1LO && n1 < N1HI) {
+        const float a0 = px[n1].x - mean, a1 = px[n1].y - mean, a2 = px[n1].z - mean,
+                    a3 = px[n1].w - mean;
+        float v0 = (a0 * rstd) * mk[j].x, v1 = (a1 * rstd) * mk[j].y;
+        float v2 = (a2 * rstd) * mk[j].z, v3 = (a3 * rstd) * mk[j].w;
+        if (STATS) {
+          px[n1] = make_float4(a0, a1, a2, a3);  // kept for the statistics below
+        }
+        A0[n1] = cmake(v0, v1);
+        A1[n1] = cmake(v2, v3);
+      } else {
+        A0[n1] = cmake(0.f, 0.f);
+        A1[n1] = cmake(0.f, 0.f);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (STATS) {
+    if (in_box_row) {  // wave-uniform; the box lies inside the support (host checks)
+#pragma unroll
+      for (int n1 = N1LO; n1 < N1HI; ++n1) {
+        const int xc = 256 * n1, x = xc + 4 * t;
+        if (xc + 256 > box.wl && xc < box.wu) {
+          const float4 a = px[n1];
+          if (xc >= box.wl && xc + 256 <= box.wu) {
+            st_s += (a.x + a.y) + (a.z + a.w);
+            st_q += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+          } else {
+            if (x >= box.wl && x < box.wu) { st_s += a.x; st_q += a.x * a.x; }
+            if (x + 1 >= box.wl && x + 1 < box.wu) { st_s += a.y; st_q += a.y * a.y; }
+            if (x + 2 >= box.wl && x + 2 < box.wu) { st_s += a.z; st_q += a.z * a.z; }
+            if (x + 3 >= box.wl && x + 3 < box.wu) { st_s += a.w; st_q += a.w * a.w; }
+          }
+        }
+      }
+    }
+  }
+  wf_dft16(A0);
+  wf_dft16(A1);
+  wf_twiddle16(A0, wA0);
+  wf_twiddle16(A1, wA1);
+
+  cfloat B0[16], B1[16];
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) slab[L.x1w_base + (k1 ^ L.x1w_mask)] = A0[k1];
+  wf_sync();
+#pragma unroll
+  for (int n2 = 0; n2 < 16; ++n2) B0[n2] = slab[L.x1r[n2 & 3] + 64 * n2];
+  wf_sync();
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) slab[L.x1w_base + (k1 ^ L.x1w_mask)] = A1[k1];
+  wf_sync();
+  // twiddles of pass B: W_128^n3 = tw_row[32 n3], n3 = 2 (t >> 4) + h
+  const cfloat sB0 = tw_row[64 * (t >> 4)], sB1 = tw_row[64 * (t >> 4) + 32];
+  wf_dft16(B0);
+  wf_twiddle16(B0, sB0);
+#pragma unroll
+  for (int n2 = 0; n2 < 16; ++n2) B1[n2] = slab[L.x1r[n2 & 3] + 64 * n2];
+  wf_sync();
+#pragma unroll
+  for (int k2 = 0; k2 < 16; ++k2) slab[L.x2w + 16 * k2] = B0[k2];
+  wf_sync();
+  wf_dft16(B1);
+  wf_twiddle16(B1, sB1);
+  cfloat Ce[4][4], Co[4][4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int n3h = 0; n3h < 4; ++n3h) Ce[s][n3h] = slab[L.x2r[s] + 256 * n3h];
+  wf_sync();
+#pragma unroll
+  for (int k2 = 0; k2 < 16; ++k2) slab[L.x2w + 16 * k2] = B1[k2];
+  wf_sync();
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int n3h = 0; n3h < 4; ++n3h) Co[s][n3h] = slab[L.x2r[s] + 256 * n3h];
+  wf_sync();
+  cfloat z[4][8], wk[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    wk[s] = tw_row[L.kbin[s]];
+    wf_dft8_pruned<KEEP>(Ce[s], Co[s], z[s]);
+  }
+  wf_unpack_lane<KEEP>(z, wk, L.self != 0, X);
+}
+
+template <int KEEP, bool STATS, int N1LO, int N1HI>
+__global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
+    const float* __restrict__ src, const int64_t* __restrict__ job_off, int64_t row_stride,
+    const float* __restrict__ mask, const float* __restrict__ mean_rstd, cfloat* __restrict__ T1,
+    const cfloat* __restrict__ tw_row, XcGeom g, XcBox box, double* __restrict__ stats_acc) {
+  __shared__ __attribute__((aligned(16))) cfloat slabs[4][WF_SLAB];
+  const int t = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  cfloat* slab = slabs[wv];
+  const int job = blockIdx.x, grp = blockIdx.y;
+  const float mean = mean_rstd ? mean_rstd[0] : 0.f;
+  const float rstd = mean_rstd ? mean_rstd[1] : 1.f;
+  const float* base = src + job_off[job];
+  const WfLane L = wf_lane(t);
+  float st_s = 0.f, st_q = 0.f;
+  cfloat* out = T1 + (int64_t)job * g.nkx * g.ny;
+  cfloat Xe[4][KEEP];  // bins of the even row of the current pair
+#pragma unroll 1
+  for (int rr = 0; rr < 4; ++rr) {
+    const int r = grp * 16 + wv * 4 + rr;  // ny % 8 == 0: a pair is in or out as a whole
+    if (r >= g.ny) break;
+    const int y = g.y0 + r;
+    const float* row = base + (int64_t)y * row_stride;
+    const float* mrow = mask + (int64_t)y * g.W;
+    const bool in_box_row = STATS && y >= box.hl && y < box.hu;
+    cfloat X[4][KEEP];
+    wf_row<KEEP, STATS, N1LO, N1HI>(row, mrow, t, L, slab, g, box, in_box_row, mean, rstd, tw_row, st_s,
+                                    st_q, X);
+    if (rr & 1) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int k3 = 0; k3 < KEEP; ++k3) {
+          const int k = L.kbin[s] + 256 * k3;
+          if (k < g.nkx)
+            *reinterpret_cast<float4*>(out + (int64_t)k * g.ny + (r - 1)) =
+                make_float4(Xe[s][k3].x, Xe[s][k3].y, X[s][k3].x, X[s][k3].y);
+        }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int k3 = 0; k3 < KEEP; ++k3) Xe[s][k3] = X[s][k3];
+    }
+  }
+  if constexpr (STATS) {
+    double ds = st_s, dq = st_q;
+    for (int o = 32; o > 0; o >>= 1) {
+      ds += __shfl_down(ds, o);
+      dq += __shfl_down(dq, o);
+    }
+    __shared__ double rs[4], rq[4];
+    if (t == 0) {
+      rs[wv] = ds;
+      rq[wv] = dq;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      ds = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+      dq = (rq[0] + rq[1]) + (rq[2] + rq[3]);
+      if (ds != 0.0 || dq != 0.0) {
+        const int slot = (blockIdx.x + 7 * blockIdx.y) & (XC_STAT_SLOTS - 1);
+        atomicAdd(&stats_acc[2 * slot], ds);
+        atomicAdd(&stats_acc[2 * slot + 1], dq);
+      }
+    }
+  }
+}
+
+// (sum, sumsq) of (x - m0) over `count` samples, spread over XC_STAT_SLOTS accumulators
+// -> fix = {mean - m0, 1/std}, out3 = {mean, 1/std, std}  (unbiased std, as
+// torch.std_mean, utils.py:81)
+__global__ void xc_stats_finalize(const double* __restrict__ acc_slots, double count,
                                   const float* __restrict__ m0, float* __restrict__ fix,
                                   float* __restrict__ out3) {
+  double acc[2] = {0.0, 0.0};
+  for (int s = 0; s < XC_STAT_SLOTS; ++s) {
+    acc[0] += acc_slots[2 * s];
+    acc[1] += acc_slots[2 * s + 1];
+  }
   const double dm = acc[0] / count;
   double var = (acc[1] - acc[0] * acc[0] / count) / (count - 1.0);
   if (var < 0) var = 0;
@@ -552,12 +767,31 @@ static int geom_from(const mc_xc_geom* q, XcGeom* g, bool rows_pow2 = true, bool
   return MC_OK;
 }
 
+// mc_xc_row_engine(): 0 = automatic (wave-per-row kernel whenever the shape fits),
+// 1 = always the workgroup-per-row kernels (A/B timing and cross-checks of the engines).
+static int g_row_engine = 0;
+static bool mc_force_wg_rows() { return g_row_engine == 1; }
+
+// The wave-per-row kernel reads samples and mask rows with 16-byte loads.  job_off[] lives
+// on the device: callers of the C ABI keep it a multiple of 4 floats whenever W == 4096
+// (whole frames: f * h * w; documented in mcorr.h).
+static bool wave_rows_aligned(const float* src, const float* mask, int64_t row_stride) {
+  return ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(mask)) & 15) == 0 &&
+         (row_stride & 3) == 0;
+}
+
 static size_t rows_lds_bytes(int N, const XcGeom& g) {
   const int sgroups = MC_WG / fft_threads(N);
   return sizeof(cfloat) * ((size_t)sgroups * 2 * lds_len(N) + (size_t)g.nkx * (g.RG + 1));
 }
 
 extern "C" {
+
+int mc_xc_row_engine(int mode) {
+  if (mode < 0 || mode > 1) return MC_ERR_ARG;
+  g_row_engine = mode;
+  return MC_OK;
+}
 
 int mc_xc_rows_lds_bytes(const mc_xc_geom* q) {
   XcGeom g;
@@ -575,10 +809,33 @@ static int rows_forward_impl(const float* src, const int64_t* job_off, int64_t r
   if (rc) return rc;
   if (!src || !job_off || !T1 || !tw_row || njobs < 1) return MC_ERR_ARG;
   const int logn = mc_ilog2(g.W) - 1;
+  XcBox b = box ? *box : XcBox{0, 0, 0, 0};
+  if (g.W == 2 * WF_N && g.nkx <= 512 && (g.ny % 8) == 0 && mask && !job_expo &&
+      wave_rows_aligned(src, mask, row_stride) &&
+      !mc_force_wg_rows()) {
+    // wave-per-row engine (mc_wave_fft.h); misaligned jobs take its element-wise loads
+    dim3 grid(njobs, (g.ny + 15) / 16);
+#define MC_WAVE_LAUNCH(KEEP, ST, LO, HI)                                                          \
+  hipLaunchKernelGGL((xc_rows_fwd_wave<KEEP, ST, LO, HI>), grid, dim3(256), 0, (hipStream_t)stream, \
+                     src, job_off, row_stride, mask, mean_rstd, (cfloat*)T1,                        \
+                     (const cfloat*)tw_row, g, b, stats_acc)
+#define MC_WAVE_PICK(KEEP, ST)                                          \
+  do {                                                                  \
+    if (g.x0 >= 256 && g.x1 <= 3840) MC_WAVE_LAUNCH(KEEP, ST, 1, 15);   \
+    else MC_WAVE_LAUNCH(KEEP, ST, 0, 16);                               \
+  } while (0)
+    if (g.nkx <= 256) {
+      if (stats_acc) MC_WAVE_PICK(1, true); else MC_WAVE_PICK(1, false);
+    } else {
+      if (stats_acc) MC_WAVE_PICK(2, true); else MC_WAVE_PICK(2, false);
+    }
+#undef MC_WAVE_PICK
+#undef MC_WAVE_LAUNCH
+    return mc_check_launch();
+  }
   const size_t lds = rows_lds_bytes(g.W / 2, g);
   if (lds > 160 * 1024) return MC_ERR_ARG;
   dim3 grid(njobs, g.ny / g.RG);
-  XcBox b = box ? *box : XcBox{0, 0, 0, 0};
   MC_DISPATCH_LOG(logn, {
     auto k = stats_acc ? xc_rows_fwd<L, true> : xc_rows_fwd<L, false>;
     if (lds > 64 * 1024)
@@ -605,7 +862,7 @@ int mc_xc_rows_forward_stats(const float* src, const int64_t* job_off, int64_t r
   if (hl < q->y0 || hu > q->y0 + q->ny || wl < q->x0 || wu > q->x1 || (wl & 1) || (wu & 1) ||
       hl >= hu || wl >= wu)
     return MC_ERR_ARG;  // the box must lie inside the region K1 reads
-  hipError_t e = hipMemsetAsync(acc, 0, 2 * sizeof(double), (hipStream_t)stream);
+  hipError_t e = hipMemsetAsync(acc, 0, 2 * XC_STAT_SLOTS * sizeof(double), (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
   XcBox box{hl, hu, wl, wu};
   int rc = rows_forward_impl(src, job_off, row_stride, nullptr, mask, m0, T1, tw_row, njobs, q, &box,

@@ -183,7 +183,7 @@ def _global_spectra(img, pl):
     # provisional mean m0 (frame 0's box) keeps the linear fix-up free of cancellation
     m0 = torch.cat([central_box_stats(img[:1])[:1], _cached(("ones2", str(dev)),
                    lambda: torch.ones(2, dtype=torch.float32, device=dev))])
-    acc = torch.empty(2, dtype=torch.float64, device=dev)
+    acc = torch.empty(128, dtype=torch.float64, device=dev)  # 64 x {sum, sumsq}
     fix = torch.empty(2, dtype=torch.float32, device=dev)
     out3 = torch.empty(3, dtype=torch.float32, device=dev)
     T1 = torch.empty((t, g.nkx, g.ny, 2), dtype=torch.float32, device=dev)
