@@ -1,9 +1,9 @@
-// CPU check of the index algebra of csrc/mc_wave_fft.h (g++ only, no GPU): the 64 lanes of
+// CPU check of the index algebra of csrc/mc_wave_fft.h (clang++ on the host, no GPU): the 64 lanes of
 // a wavefront are executed one after the other, phase by phase, over a shared 1024-entry
 // slab exactly as xc_rows_fwd_wave does, and the 4 * KEEP real-FFT bins every lane ends
 // up with are compared with a double-precision DFT of the same real row.
 //
-//   g++ -O1 -I torch_motion_correction_amd/csrc tests/host_wave_fft.cpp -o /tmp/host_wave_fft && /tmp/host_wave_fft
+//   /opt/rocm/lib/llvm/bin/clang++ -O1 -std=c++17 -I torch_motion_correction_amd/csrc tests/host_wave_fft.cpp -o /tmp/host_wave_fft -lm && /tmp/host_wave_fft
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -11,47 +11,50 @@
 
 #include "mc_wave_fft.h"
 
-static cfloat tw4096(int k) {
+static wf2 tw4096(int k) {
   const double a = -2.0 * M_PI * (double)k / 4096.0;
-  return cmake((float)cos(a), (float)sin(a));
+  return wf_make((float)cos(a), (float)sin(a));
 }
 
 template <int KEEP>
 static double run(unsigned seed, int x0, int x1) {
   std::vector<float> row(4096);
   srand(seed);
-  for (int i = 0; i < 4096; ++i) row[i] = (i >= x0 && i < x1) ? (float)rand() / RAND_MAX - 0.5f : 0.f;
-  static cfloat A0[64][16], A1[64][16], B0[64][16], B1[64][16], Ce[64][4][4], Co[64][4][4];
-  static cfloat slab[WF_SLAB];
+  for (int i = 0; i < 4096; ++i) row[i] = (i >= x0 && i < x1) ? (float)(rand() % 65536) / 65536.f - 0.5f : 0.f;
+  static wf2 A0[64][16], A1[64][16], B0[64][16], B1[64][16], Ce[64][4][4], Co[64][4][4];
+  static wf2 slab[WF_SLAB];
   WfLane L[64];
   for (int t = 0; t < 64; ++t) L[t] = wf_lane(t);
   // pass A
   for (int t = 0; t < 64; ++t) {
     for (int n1 = 0; n1 < 16; ++n1) {
       const int x = 256 * n1 + 4 * t;
-      A0[t][n1] = cmake(row[x], row[x + 1]);
-      A1[t][n1] = cmake(row[x + 2], row[x + 3]);
+      A0[t][n1] = wf_make(row[x], row[x + 1]);
+      A1[t][n1] = wf_make(row[x + 2], row[x + 3]);
     }
     wf_dft16(A0[t]);
     wf_dft16(A1[t]);
-    wf_twiddle16(A0[t], tw4096(4 * t));
-    wf_twiddle16(A1[t], tw4096(4 * t + 2));
+    for (int k1 = 1; k1 < 16; ++k1) {  // twA[k1 - 1][q] = W_2048^{q k1} = tw4096(2 q k1)
+      A0[t][k1] = wf_cmul(A0[t][k1], tw4096(2 * (2 * t) * k1));
+      A1[t][k1] = wf_cmul(A1[t][k1], tw4096(2 * (2 * t + 1) * k1));
+    }
   }
   // exchange 1, pass B
   for (int h = 0; h < 2; ++h) {
-    for (int i = 0; i < WF_SLAB; ++i) slab[i] = cmake(NAN, NAN);
+    for (int i = 0; i < WF_SLAB; ++i) slab[i] = wf_make(NAN, NAN);
     for (int t = 0; t < 64; ++t)
       for (int k1 = 0; k1 < 16; ++k1) slab[L[t].x1w_base + (k1 ^ L[t].x1w_mask)] = (h ? A1 : A0)[t][k1];
     for (int t = 0; t < 64; ++t) {
-      cfloat(&B)[16] = (h ? B1 : B0)[t];
+      wf2(&B)[16] = (h ? B1 : B0)[t];
       for (int n2 = 0; n2 < 16; ++n2) B[n2] = slab[L[t].x1r[n2 & 3] + 64 * n2];
       wf_dft16(B);
-      wf_twiddle16(B, tw4096(64 * (t >> 4) + 32 * h));
+      // twB[g][k2 - 1][h] = W_128^{(2 g + h) k2} = tw4096(32 (2 g + h) k2)
+      for (int k2 = 1; k2 < 16; ++k2) B[k2] = wf_cmul(B[k2], tw4096(32 * (2 * (t >> 4) + h) * k2));
     }
   }
   // exchange 2
   for (int h = 0; h < 2; ++h) {
-    for (int i = 0; i < WF_SLAB; ++i) slab[i] = cmake(NAN, NAN);
+    for (int i = 0; i < WF_SLAB; ++i) slab[i] = wf_make(NAN, NAN);
     for (int t = 0; t < 64; ++t)
       for (int k2 = 0; k2 < 16; ++k2) slab[L[t].x2w + 16 * k2] = (h ? B1 : B0)[t][k2];
     for (int t = 0; t < 64; ++t)
@@ -69,9 +72,9 @@ static double run(unsigned seed, int x0, int x1) {
   double worst = 0.0, scale = 0.0;
   std::vector<int> seen(512, 0);
   for (int t = 0; t < 64; ++t) {
-    cfloat z[4][8], wk[4], X[4][KEEP];
+    wf2 z[4][8], wk[4], X[4][KEEP];
     for (int s = 0; s < 4; ++s) {
-      for (int i = 0; i < 8; ++i) z[s][i] = cmake(NAN, NAN);
+      for (int i = 0; i < 8; ++i) z[s][i] = wf_make(NAN, NAN);
       wk[s] = tw4096(L[t].kbin[s]);
       wf_dft8_pruned<KEEP>(Ce[t][s], Co[t][s], z[s]);
     }

@@ -18,8 +18,15 @@
 // needs no third exchange.  Only the bins k3 in {0..KEEP-1} and {8-KEEP..7} of every
 // radix-8 butterfly are used (band-pass pruning): the rest is dead code.
 //
-// The lane-level functions below are __host__ __device__ so that tests/host_wave_fft.cpp
-// can run the identical index algebra lane by lane on the CPU (g++, no GPU needed).
+// Arithmetic is written on 2-float vectors (re, im) so that it maps onto the packed fp32
+// VALU instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: one instruction per
+// complex add, two per complex multiply); the rotations by -i and the (-im, re) operand of
+// a complex multiply are expressed through the instructions' op_sel / neg modifiers
+// (inline asm), which cost nothing.  The kernel is VALU-issue bound, so the instruction
+// count is what matters.
+//
+// The lane-level functions are __host__ __device__ so that tests/host_wave_fft.cpp can
+// run the identical index algebra lane by lane on the CPU (clang++, no GPU needed).
 #pragma once
 
 #ifdef __HIPCC__
@@ -31,38 +38,73 @@
 struct cfloat {
   float x, y;
 };
-static inline cfloat cmake(float a, float b) { return cfloat{a, b}; }
-static inline cfloat cadd(cfloat a, cfloat b) { return cfloat{a.x + b.x, a.y + b.y}; }
-static inline cfloat csub(cfloat a, cfloat b) { return cfloat{a.x - b.x, a.y - b.y}; }
-static inline cfloat cmul(cfloat a, cfloat b) {
-  return cfloat{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
-}
-static inline cfloat cconj(cfloat a) { return cfloat{a.x, -a.y}; }
 #define MC_HD static inline
 #endif
+
+typedef float wf2 __attribute__((ext_vector_type(2)));  // (re, im)
 
 #define WF_N 2048       // complex points per line
 #define WF_SLAB 1024    // complex entries of a wave's LDS slab (8 KiB)
 
-// multiply by the compile-time constant (cr, ci)
-MC_HD cfloat wf_cmulc(cfloat a, float cr, float ci) {
-  return cmake(a.x * cr - a.y * ci, a.x * ci + a.y * cr);
+MC_HD wf2 wf_make(float re, float im) { return wf2{re, im}; }
+MC_HD wf2 wf_from(cfloat c) { return wf2{c.x, c.y}; }
+MC_HD cfloat wf_to(wf2 v) { return cfloat{v.x, v.y}; }
+
+// a + (-i) b = (a.re + b.im, a.im - b.re)   and   a - (-i) b
+MC_HD wf2 wf_add_mi(wf2 a, wf2 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  wf2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#else
+  return wf2{a.x + b.y, a.y - b.x};
+#endif
 }
-// multiply by -i (forward transforms only need this one)
-MC_HD cfloat wf_mul_mi(cfloat a) { return cmake(a.y, -a.x); }
+MC_HD wf2 wf_sub_mi(wf2 a, wf2 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  wf2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#else
+  return wf2{a.x - b.y, a.y + b.x};
+#endif
+}
+// complex product a * w = a.re * (w.re, w.im) + a.im * (-w.im, w.re)
+MC_HD wf2 wf_cmul(wf2 a, wf2 w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  wf2 t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+      : "=v"(r)
+      : "v"(a), "v"(w), "v"(t));
+  return r;
+#else
+  return wf2{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x};
+#endif
+}
+// a + w * b  and  a - w * b  with a compile-time constant w = (cr, ci): the butterflies'
+// internal twiddles folded into the following add (two packed FMAs each)
+MC_HD wf2 wf_fma_c(wf2 a, wf2 b, float cr, float ci) {
+  const wf2 c = {cr, ci}, cs = {-ci, cr};
+  return __builtin_elementwise_fma(b.yy, cs, __builtin_elementwise_fma(b.xx, c, a));
+}
+MC_HD wf2 wf_cmulc(wf2 a, float cr, float ci) {
+  const wf2 c = {cr, ci}, cs = {-ci, cr};
+  return __builtin_elementwise_fma(a.yy, cs, a.xx * c);
+}
 
 // forward radix-4 butterfly, natural order out
-MC_HD void wf_bfly4(cfloat& a0, cfloat& a1, cfloat& a2, cfloat& a3) {
-  const cfloat t0 = cadd(a0, a2), t1 = csub(a0, a2);
-  const cfloat t2 = cadd(a1, a3), t3 = wf_mul_mi(csub(a1, a3));
-  a0 = cadd(t0, t2);
-  a1 = cadd(t1, t3);
-  a2 = csub(t0, t2);
-  a3 = csub(t1, t3);
+MC_HD void wf_bfly4(wf2& a0, wf2& a1, wf2& a2, wf2& a3) {
+  const wf2 t0 = a0 + a2, t1 = a0 - a2;
+  const wf2 t2 = a1 + a3, d = a1 - a3;
+  a0 = t0 + t2;
+  a2 = t0 - t2;
+  a1 = wf_add_mi(t1, d);
+  a3 = wf_sub_mi(t1, d);
 }
 
 // forward 16-point DFT in place, natural order in and out:  n = j + 4 m,  k = p + 4 r
-MC_HD void wf_dft16(cfloat (&a)[16]) {
+MC_HD void wf_dft16(wf2 (&a)[16]) {
   const float C1 = 0.92387953251128673848f, S1 = 0.38268343236508978178f;
   const float H = 0.70710678118654752440f;
 #pragma unroll
@@ -72,19 +114,31 @@ MC_HD void wf_dft16(cfloat (&a)[16]) {
   a[1 + 8] = wf_cmulc(a[1 + 8], H, -H);     // W^2
   a[1 + 12] = wf_cmulc(a[1 + 12], S1, -C1); // W^3
   a[2 + 4] = wf_cmulc(a[2 + 4], H, -H);     // W^2
-  a[2 + 8] = wf_mul_mi(a[2 + 8]);           // W^4
+  // a[2 + 8] * W^4 = -i a[2 + 8]: folded into the second stage below
   a[2 + 12] = wf_cmulc(a[2 + 12], -H, -H);  // W^6
   a[3 + 4] = wf_cmulc(a[3 + 4], S1, -C1);   // W^3
   a[3 + 8] = wf_cmulc(a[3 + 8], -H, -H);    // W^6
   a[3 + 12] = wf_cmulc(a[3 + 12], -C1, S1); // W^9
 #pragma unroll
-  for (int p = 0; p < 4; ++p) wf_bfly4(a[4 * p], a[4 * p + 1], a[4 * p + 2], a[4 * p + 3]);
-  // a[4 p + r] = X[p + 4 r]  ->  transpose to natural order
+  for (int p = 0; p < 4; ++p) {
+    wf2 &b0 = a[4 * p], &b1 = a[4 * p + 1], &b2 = a[4 * p + 2], &b3 = a[4 * p + 3];
+    if (p == 2) {  // b2 stands for -i b2
+      const wf2 t0 = wf_add_mi(b0, b2), t1 = wf_sub_mi(b0, b2);
+      const wf2 t2 = b1 + b3, d = b1 - b3;
+      b0 = t0 + t2;
+      b2 = t0 - t2;
+      b1 = wf_add_mi(t1, d);
+      b3 = wf_sub_mi(t1, d);
+    } else {
+      wf_bfly4(b0, b1, b2, b3);
+    }
+  }
+  // a[4 p + r] = X[p + 4 r]  ->  transpose to natural order (register renaming only)
 #pragma unroll
   for (int p = 0; p < 4; ++p)
 #pragma unroll
     for (int r = p + 1; r < 4; ++r) {
-      const cfloat s = a[4 * p + r];
+      const wf2 s = a[4 * p + r];
       a[4 * p + r] = a[4 * r + p];
       a[4 * r + p] = s;
     }
@@ -93,46 +147,25 @@ MC_HD void wf_dft16(cfloat (&a)[16]) {
 // forward 8-point DFT, natural order in (e = even inputs n3 = 0,2,4,6; o = odd inputs
 // 1,3,5,7); only outputs 0, 1, 6, 7 (KEEP = 2) or 0, 7 (KEEP = 1) are produced
 template <int KEEP>
-MC_HD void wf_dft8_pruned(const cfloat (&e)[4], const cfloat (&o)[4], cfloat (&z)[8]) {
+MC_HD void wf_dft8_pruned(const wf2 (&e)[4], const wf2 (&o)[4], wf2 (&z)[8]) {
   const float H = 0.70710678118654752440f;
-  cfloat e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
-  cfloat o0 = o[0], o1 = o[1], o2 = o[2], o3 = o[3];
+  wf2 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
+  wf2 o0 = o[0], o1 = o[1], o2 = o[2], o3 = o[3];
   wf_bfly4(e0, e1, e2, e3);  // E[0..3]
   wf_bfly4(o0, o1, o2, o3);  // O[0..3]
-  // X[k] = E[k & 3] + W_8^k O[k & 3]
-  z[0] = cadd(e0, o0);
-  z[7] = csub(e3, wf_cmulc(o3, -H, -H));  // W^7 = -W^3, W^3 = (-H, -H)
+  // X[k] = E[k & 3] + W_8^k O[k & 3];  W^1 = (H,-H), W^2 = -i, W^3 = (-H,-H), W^{k+4} = -W^k
+  z[0] = e0 + o0;
+  z[7] = wf_fma_c(e3, o3, H, H);  // W^7 = -W^3
   if (KEEP >= 2) {
-    z[1] = cadd(e1, wf_cmulc(o1, H, -H));  // W^1
-    z[6] = csub(e2, wf_mul_mi(o2));        // W^6 = -W^2, W^2 = -i
+    z[1] = wf_fma_c(e1, o1, H, -H);
+    z[6] = wf_sub_mi(e2, o2);  // W^6 = -W^2 = +i
   }
   if (KEEP >= 4) {
-    z[2] = cadd(e2, wf_mul_mi(o2));
-    z[3] = cadd(e3, wf_cmulc(o3, -H, -H));
-    z[4] = csub(e0, o0);
-    z[5] = csub(e1, wf_cmulc(o1, H, -H));
+    z[2] = wf_add_mi(e2, o2);
+    z[3] = wf_fma_c(e3, o3, -H, -H);
+    z[4] = e0 - o0;
+    z[5] = wf_fma_c(e1, o1, -H, H);
   }
-}
-
-// w^1 .. w^15 from w^1 (depth <= 4 products), applied to a[1..15]
-MC_HD void wf_twiddle16(cfloat (&a)[16], cfloat w1) {
-  const cfloat w2 = cmul(w1, w1), w4 = cmul(w2, w2), w8 = cmul(w4, w4);
-  const cfloat w3 = cmul(w2, w1), w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
-  a[1] = cmul(a[1], w1);
-  a[2] = cmul(a[2], w2);
-  a[3] = cmul(a[3], w3);
-  a[4] = cmul(a[4], w4);
-  a[5] = cmul(a[5], w5);
-  a[6] = cmul(a[6], w6);
-  a[7] = cmul(a[7], w7);
-  a[8] = cmul(a[8], w8);
-  a[9] = cmul(a[9], cmul(w8, w1));
-  a[10] = cmul(a[10], cmul(w8, w2));
-  a[11] = cmul(a[11], cmul(w8, w3));
-  a[12] = cmul(a[12], cmul(w8, w4));
-  a[13] = cmul(a[13], cmul(w8, w5));
-  a[14] = cmul(a[14], cmul(w8, w6));
-  a[15] = cmul(a[15], cmul(w8, w7));
 }
 
 // ------------------------------------------------------------------ lane geometry
@@ -168,27 +201,27 @@ MC_HD WfLane wf_lane(int t) {
   return L;
 }
 
-// Real-FFT unpack of one bin: Zk = Z[k], Zm = Z[N - k] (not yet conjugated), wk = w^k.
-MC_HD cfloat wf_unpack(cfloat zk, cfloat zmr, cfloat wk) {
-  const cfloat zm = cconj(zmr);
-  const cfloat sm = cadd(zk, zm), d = csub(zk, zm);
-  const cfloat wd = cmul(wk, d);  // -i * wd = (wd.y, -wd.x)
-  return cmake(0.5f * (sm.x + wd.y), 0.5f * (sm.y - wd.x));
+// Real-FFT unpack of one bin: zk = Z[k], zmr = Z[N - k] (not yet conjugated), wk = w^k.
+//   X = 0.5 * ((zk + conj zm) - i * wk * (zk - conj zm))
+MC_HD wf2 wf_unpack(wf2 zk, wf2 zmr, wf2 wk) {
+  const wf2 zm = {zmr.x, -zmr.y};
+  const wf2 sm = zk + zm, d = zk - zm;
+  const wf2 wd = wf_cmul(d, wk);
+  return wf_add_mi(sm, wd) * 0.5f;
 }
 
 // From the pruned outputs of a lane's four radix-8 butterflies to its 4 * KEEP real-FFT
 // bins:  X[s][k3] is bin kbin[s] + 256 k3.  wk[s] = w^{kbin[s]}.
 template <int KEEP>
-MC_HD void wf_unpack_lane(const cfloat (&z)[4][8], const cfloat (&wk)[4], bool self,
-                          cfloat (&X)[4][KEEP]) {
+MC_HD void wf_unpack_lane(const wf2 (&z)[4][8], const wf2 (&wk)[4], bool self, wf2 (&X)[4][KEEP]) {
   const float C1 = 0.92387953251128673848f, S1 = 0.38268343236508978178f;  // w^256
 #pragma unroll
   for (int k3 = 0; k3 < KEEP; ++k3) {
     // general lanes: slot s pairs with slot s ^ 1 at 7 - k3; lane 0: a0 pairs with a0 at
     // (8 - k3) & 7, a1 with a1 at 7 - k3
-    const cfloat m_a0 = self ? z[0][(8 - k3) & 7] : z[1][7 - k3];
-    const cfloat m_a1 = self ? z[1][7 - k3] : z[0][7 - k3];
-    cfloat w[4] = {wk[0], wk[1], wk[2], wk[3]};
+    const wf2 m_a0 = self ? z[0][(8 - k3) & 7] : z[1][7 - k3];
+    const wf2 m_a1 = self ? z[1][7 - k3] : z[0][7 - k3];
+    wf2 w[4] = {wk[0], wk[1], wk[2], wk[3]};
     if (k3 == 1) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) w[s] = wf_cmulc(w[s], C1, -S1);

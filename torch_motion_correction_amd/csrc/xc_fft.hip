@@ -18,6 +18,7 @@
 //   K6 xc_peak_nbhd        re-evaluate rows y-1,y,y+1 of one map for the parabola fit
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include "mc_fft.h"
 #include "mc_wave_fft.h"
 #include "mcorr.h"
@@ -175,86 +176,126 @@ __device__ __forceinline__ void wf_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Scheduling pin: `v` (an index / offset every later address is derived from) becomes
+// opaque at the point where `dep` has been computed, so the loads that use it cannot be
+// hoisted above that point (the compiler otherwise issues every table read at the top of
+// the row and pays for it with ~60 registers each).
+__device__ __forceinline__ void wf_pin(int& v, float dep) { asm volatile("" : "+v"(v) : "v"(dep)); }
+
 #define XC_STAT_SLOTS 64  // stats_acc = XC_STAT_SLOTS x {sum, sumsq} doubles
 
-// N1LO / N1HI: the 256-sample chunks [N1LO, N1HI) of a row can touch the mask support;
-// the others are zero and are not loaded at all.
-template <int KEEP, bool STATS, int N1LO, int N1HI>
-__device__ __forceinline__ void wf_row(const float* __restrict__ row, const float* __restrict__ mrow,
-                                       int t, const WfLane& L, cfloat* slab, const XcGeom& g,
-                                       const XcBox& box, bool in_box_row, float mean, float rstd,
-                                       const cfloat* __restrict__ tw_row,
-                                       float& st_s, float& st_q, cfloat (&X)[4][KEEP]) {
-  cfloat A0[16], A1[16];
-  // Branch-free loads.  Samples: a lane whose quad lies outside the support [x0, x1) reads
-  // the nearest quad inside it instead (a line its neighbours fetch anyway: no extra HBM
-  // traffic) and is then multiplied by the mask's exact zero.  Mask rows (L2-resident):
-  // read as they are, in four groups behind the samples so that only one group of mask
-  // registers is live at a time.
+// Twiddles come from two LDS tables shared by the workgroup's four waves (filled once from
+// tw_row, exact table values instead of products of a base twiddle):
+//   twA[k1 - 1][q]       = W_2048^{q k1}        k1 = 1..15, q < 128   (15 KiB)
+//   twB[g][k2 - 1][h]    = W_128^{(2 g + h) k2}  k2 = 1..15            (960 B)
+// Lane t reads twA[k1-1][2t..2t+1] and twB[t>>4][k2-1][0..1] as one 16-byte LDS read each
+// (the latter a broadcast within 16 lanes).
+#define WF_TWA (15 * 128)
+#define WF_TWB (4 * 15 * 2)
+#define WF_ROWS_PER_WG 16  // 4 rows (two pairs) per wave
+#define WF_PREFETCH_DEFAULT 1  // 1: next row's samples, 2: and mask row, loaded under the current transform
+
+// N1LO / N1HI: only the 256-sample chunks [N1LO, N1HI) of a row can touch the mask support,
+// the others are zero and are not loaded.  CLAMP_ALL = false: the chunks strictly between
+// N1LO and N1HI - 1 lie wholly inside the support (host checks) and load unclamped.
+// Statistics: box.wl / box.wu are multiples of 256 (host checks), so a chunk is inside
+// the box or outside it as a whole.
+template <int N1LO, int N1HI, bool CLAMP_ALL>
+__device__ __forceinline__ void wf_load_px(const float* __restrict__ row, int t, const XcGeom& g,
+                                           float4 (&px)[16]) {
+  // Branch-free: a lane whose quad lies outside the support [x0, x1) reads the nearest quad
+  // inside it instead (a line its neighbours fetch anyway: no extra HBM traffic); the value
+  // is later multiplied by the mask's exact zero.
   const int xlo = g.x0 & ~3, xhi = ((g.x1 + 3) & ~3) - 4;
-  float4 px[16];
 #pragma unroll
   for (int n1 = N1LO; n1 < N1HI; ++n1) {
     const int x = 256 * n1 + 4 * t;
-    const int xs = x < xlo ? xlo : (x > xhi ? xhi : x);
-    px[n1] = *reinterpret_cast<const float4*>(row + xs);
-  }
-  // twiddles of pass A: W_2048^q = tw_row[2 q], q = 2 t, 2 t + 1 (L1-resident table)
-  const cfloat wA0 = tw_row[4 * t], wA1 = tw_row[4 * t + 2];
-#pragma unroll
-  for (int grp4 = 0; grp4 < 4; ++grp4) {
-    float4 mk[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n1 = 4 * grp4 + j;
-      if (n1 >= N1LO && n1 < N1HI) mk[j] = *reinterpret_cast<const float4*>(mrow + 256 * n1 + 4 * t);
+    if (CLAMP_ALL || n1 == N1LO || n1 == N1HI - 1) {
+      const int xs = min(max(x, xlo), xhi);
+      px[n1] = *reinterpret_cast<const float4*>(row + xs);
+    } else {
+      px[n1] = *reinterpret_cast<const float4*>(row + x);
     }
+  }
+}
+
+template <int N1LO, int N1HI>
+__device__ __forceinline__ void wf_load_mask(const float* __restrict__ mrow, int t, float4 (&mk)[16]) {
+  // mask rows (L2-resident) are read as they are: exact zeros outside the support
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n1 = 4 * grp4 + j;
+  for (int n1 = N1LO; n1 < N1HI; ++n1) mk[n1] = *reinterpret_cast<const float4*>(mrow + 256 * n1 + 4 * t);
+}
+
+// One row.  PREFETCH 0: px / mk are loaded here.  1: px holds this row's samples on entry
+// and the next row's on exit (loaded right after the current ones were consumed, so the
+// HBM latency of row i+1 hides behind the transform of row i); 2: the same for mk too.
+// next_row / next_mrow are null after the last row (wave-uniform).
+template <int KEEP, bool STATS, int N1LO, int N1HI, bool CLAMP_ALL, int PREFETCH>
+__device__ __forceinline__ void wf_row(float4 (&px)[16], float4 (&mk)[16],
+                                       const float* __restrict__ row, const float* __restrict__ mrow,
+                                       const float* __restrict__ next_row,
+                                       const float* __restrict__ next_mrow, int t, wf2* slab,
+                                       const cfloat* twA, const cfloat* twB, const cfloat* twK,
+                                       const XcGeom& g, int box_lo, int box_hi, float mean, float rstd,
+                                       float& st_s, float& st_q, wf2 (&X)[4][KEEP]) {
+  wf2 A0[16], A1[16];
+  if (PREFETCH < 1) wf_load_px<N1LO, N1HI, CLAMP_ALL>(row, t, g, px);
+  if (PREFETCH < 2) wf_load_mask<N1LO, N1HI>(mrow, t, mk);
+  auto condition = [&](auto in_box) {
+    constexpr bool INBOX = decltype(in_box)::value;
+    wf2 acc_s = {0.f, 0.f}, acc_q = {0.f, 0.f};
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
       if (n1 >= N1LO && n1 < N1HI) {
-        const float a0 = px[n1].x - mean, a1 = px[n1].y - mean, a2 = px[n1].z - mean,
-                    a3 = px[n1].w - mean;
-        float v0 = (a0 * rstd) * mk[j].x, v1 = (a1 * rstd) * mk[j].y;
-        float v2 = (a2 * rstd) * mk[j].z, v3 = (a3 * rstd) * mk[j].w;
-        if (STATS) {
-          px[n1] = make_float4(a0, a1, a2, a3);  // kept for the statistics below
+        const wf2 a01 = wf2{px[n1].x, px[n1].y} - mean, a23 = wf2{px[n1].z, px[n1].w} - mean;
+        if (INBOX) {  // chunk weight 1 inside the box, 0 outside (scalar): no branch per chunk
+          const float cw = (n1 >= box_lo && n1 < box_hi) ? 1.f : 0.f;
+          const wf2 sa = a01 + a23;
+          const wf2 sq = __builtin_elementwise_fma(a01, a01, a23 * a23);
+          acc_s = __builtin_elementwise_fma(sa, wf2{cw, cw}, acc_s);
+          acc_q = __builtin_elementwise_fma(sq, wf2{cw, cw}, acc_q);
         }
-        A0[n1] = cmake(v0, v1);
-        A1[n1] = cmake(v2, v3);
+        A0[n1] = (a01 * rstd) * wf2{mk[n1].x, mk[n1].y};
+        A1[n1] = (a23 * rstd) * wf2{mk[n1].z, mk[n1].w};
       } else {
-        A0[n1] = cmake(0.f, 0.f);
-        A1[n1] = cmake(0.f, 0.f);
+        A0[n1] = wf2{0.f, 0.f};
+        A1[n1] = wf2{0.f, 0.f};
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (STATS) {
-    if (in_box_row) {  // wave-uniform; the box lies inside the support (host checks)
-#pragma unroll
-      for (int n1 = N1LO; n1 < N1HI; ++n1) {
-        const int xc = 256 * n1, x = xc + 4 * t;
-        if (xc + 256 > box.wl && xc < box.wu) {
-          const float4 a = px[n1];
-          if (xc >= box.wl && xc + 256 <= box.wu) {
-            st_s += (a.x + a.y) + (a.z + a.w);
-            st_q += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
-          } else {
-            if (x >= box.wl && x < box.wu) { st_s += a.x; st_q += a.x * a.x; }
-            if (x + 1 >= box.wl && x + 1 < box.wu) { st_s += a.y; st_q += a.y * a.y; }
-            if (x + 2 >= box.wl && x + 2 < box.wu) { st_s += a.z; st_q += a.z * a.z; }
-            if (x + 3 >= box.wl && x + 3 < box.wu) { st_s += a.w; st_q += a.w * a.w; }
-          }
-        }
-      }
+    if (INBOX) {
+      st_s += acc_s.x + acc_s.y;
+      st_q += acc_q.x + acc_q.y;
+    }
+  };
+  if (STATS && box_hi > box_lo) condition(std::true_type{});  // wave-uniform: a row of the box
+  else condition(std::false_type{});
+  int tl = t;  // lane index as the tables see it (re-pinned before each table)
+  wf_pin(tl, A0[N1HI - 1].x);
+  const WfLane L = wf_lane(tl);  // slab addresses: derived here, not carried across rows
+  if (PREFETCH >= 1) {
+    if (next_row) {  // issued once this row's samples have been consumed, not earlier
+      int tp = t;
+      wf_pin(tp, A1[N1HI - 1].y);
+      wf_load_px<N1LO, N1HI, CLAMP_ALL>(next_row, tp, g, px);
+      if (PREFETCH >= 2) wf_load_mask<N1LO, N1HI>(next_mrow, tp, mk);
     }
   }
   wf_dft16(A0);
-  wf_dft16(A1);
-  wf_twiddle16(A0, wA0);
-  wf_twiddle16(A1, wA1);
+  wf_pin(tl, A0[15].y);  // table reads fly under the second butterfly
+  {
+    const float4* twa = reinterpret_cast<const float4*>(twA) + tl;  // [k1-1][64 lanes] of 16 B
+    float4 w[15];
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) w[k1 - 1] = twa[(k1 - 1) * 64];
+    wf_dft16(A1);
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) {
+      A0[k1] = wf_cmul(A0[k1], wf2{w[k1 - 1].x, w[k1 - 1].y});
+      A1[k1] = wf_cmul(A1[k1], wf2{w[k1 - 1].z, w[k1 - 1].w});
+    }
+  }
 
-  cfloat B0[16], B1[16];
+  wf2 B0[16], B1[16];
 #pragma unroll
   for (int k1 = 0; k1 < 16; ++k1) slab[L.x1w_base + (k1 ^ L.x1w_mask)] = A0[k1];
   wf_sync();
@@ -264,19 +305,27 @@ __device__ __forceinline__ void wf_row(const float* __restrict__ row, const floa
 #pragma unroll
   for (int k1 = 0; k1 < 16; ++k1) slab[L.x1w_base + (k1 ^ L.x1w_mask)] = A1[k1];
   wf_sync();
-  // twiddles of pass B: W_128^n3 = tw_row[32 n3], n3 = 2 (t >> 4) + h
-  const cfloat sB0 = tw_row[64 * (t >> 4)], sB1 = tw_row[64 * (t >> 4) + 32];
   wf_dft16(B0);
-  wf_twiddle16(B0, sB0);
 #pragma unroll
   for (int n2 = 0; n2 < 16; ++n2) B1[n2] = slab[L.x1r[n2 & 3] + 64 * n2];
   wf_sync();
+  wf_pin(tl, B0[15].y);
+  {
+    const float4* twb = reinterpret_cast<const float4*>(twB) + (tl >> 4) * 15;
+    float4 w[15];
+#pragma unroll
+    for (int k2 = 1; k2 < 16; ++k2) w[k2 - 1] = twb[k2 - 1];
+    wf_dft16(B1);
+#pragma unroll
+    for (int k2 = 1; k2 < 16; ++k2) {
+      B0[k2] = wf_cmul(B0[k2], wf2{w[k2 - 1].x, w[k2 - 1].y});
+      B1[k2] = wf_cmul(B1[k2], wf2{w[k2 - 1].z, w[k2 - 1].w});
+    }
+  }
 #pragma unroll
   for (int k2 = 0; k2 < 16; ++k2) slab[L.x2w + 16 * k2] = B0[k2];
   wf_sync();
-  wf_dft16(B1);
-  wf_twiddle16(B1, sB1);
-  cfloat Ce[4][4], Co[4][4];
+  wf2 Ce[4][4], Co[4][4];
 #pragma unroll
   for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -290,44 +339,88 @@ __device__ __forceinline__ void wf_row(const float* __restrict__ row, const floa
 #pragma unroll
     for (int n3h = 0; n3h < 4; ++n3h) Co[s][n3h] = slab[L.x2r[s] + 256 * n3h];
   wf_sync();
-  cfloat z[4][8], wk[4];
+  wf_pin(tl, Ce[0][0].x);
+  wf2 z[4][8], wk[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    wk[s] = tw_row[L.kbin[s]];
+    wk[s] = wf_from(twK[64 * s + tl]);
     wf_dft8_pruned<KEEP>(Ce[s], Co[s], z[s]);
   }
   wf_unpack_lane<KEEP>(z, wk, L.self != 0, X);
 }
 
-template <int KEEP, bool STATS, int N1LO, int N1HI>
+template <int KEEP, bool STATS, int N1LO, int N1HI, bool CLAMP_ALL, int WF_PREFETCH>
 __global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
     const float* __restrict__ src, const int64_t* __restrict__ job_off, int64_t row_stride,
     const float* __restrict__ mask, const float* __restrict__ mean_rstd, cfloat* __restrict__ T1,
     const cfloat* __restrict__ tw_row, XcGeom g, XcBox box, double* __restrict__ stats_acc) {
   __shared__ __attribute__((aligned(16))) cfloat slabs[4][WF_SLAB];
+  __shared__ __attribute__((aligned(16))) cfloat tab[WF_TWA + WF_TWB + 256];
+  const cfloat* twA = tab;
+  const cfloat* twB = tab + WF_TWA;
+  const cfloat* twK = tab + WF_TWA + WF_TWB;  // [slot][lane] = w^kbin
   const int t = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  cfloat* slab = slabs[wv];
+  wf2* slab = reinterpret_cast<wf2*>(slabs[wv]);
   const int job = blockIdx.x, grp = blockIdx.y;
+  {  // tables from tw_row[k] = exp(-2 pi i k / 4096): W_2048^m = tw_row[2 m], W_128^m =
+     // tw_row[32 m]; all loads issued before the first LDS write
+    constexpr int NTAB = WF_TWA + WF_TWB + 256, PER = (NTAB + 255) / 256;
+    cfloat tv[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      int i = threadIdx.x + 256 * j;
+      i = i < NTAB ? i : NTAB - 1;
+      int src_k;
+      if (i < WF_TWA) {
+        src_k = 2 * (i & 127) * ((i >> 7) + 1);
+      } else if (i < WF_TWA + WF_TWB) {
+        const int e = i - WF_TWA, h = e & 1, k2 = ((e >> 1) % 15) + 1, gq = e / 30;
+        src_k = 32 * (2 * gq + h) * k2;
+      } else {
+        const int e = i - WF_TWA - WF_TWB, sl = e >> 6, l = e & 63;
+        src_k = sl == 0 ? l : (sl == 1 ? (l == 0 ? 128 : 256 - l) : (sl == 2 ? 64 + l : 192 - l));
+      }
+      tv[j] = tw_row[src_k];
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = threadIdx.x + 256 * j;
+      if (i < NTAB) tab[i] = tv[j];
+    }
+  }
   const float mean = mean_rstd ? mean_rstd[0] : 0.f;
   const float rstd = mean_rstd ? mean_rstd[1] : 1.f;
   const float* base = src + job_off[job];
-  const WfLane L = wf_lane(t);
   float st_s = 0.f, st_q = 0.f;
   cfloat* out = T1 + (int64_t)job * g.nkx * g.ny;
-  cfloat Xe[4][KEEP];  // bins of the even row of the current pair
+  const int r_first = grp * WF_ROWS_PER_WG + wv * (WF_ROWS_PER_WG / 4);
+  int nrows = g.ny - r_first;  // ny % 8 == 0: a pair is in or out as a whole
+  nrows = nrows < 0 ? 0 : (nrows > WF_ROWS_PER_WG / 4 ? WF_ROWS_PER_WG / 4 : nrows);
+  float4 px[16], mk[16];
+  if (WF_PREFETCH >= 1 && nrows > 0)
+    wf_load_px<N1LO, N1HI, CLAMP_ALL>(base + (int64_t)(g.y0 + r_first) * row_stride, t, g, px);
+  if (WF_PREFETCH >= 2 && nrows > 0)
+    wf_load_mask<N1LO, N1HI>(mask + (int64_t)(g.y0 + r_first) * g.W, t, mk);
+  __syncthreads();
+  wf2 Xe[4][KEEP];  // bins of the even row of the current pair
 #pragma unroll 1
-  for (int rr = 0; rr < 4; ++rr) {
-    const int r = grp * 16 + wv * 4 + rr;  // ny % 8 == 0: a pair is in or out as a whole
-    if (r >= g.ny) break;
+  for (int rr = 0; rr < nrows; ++rr) {
+    const int r = r_first + rr;
     const int y = g.y0 + r;
     const float* row = base + (int64_t)y * row_stride;
     const float* mrow = mask + (int64_t)y * g.W;
+    const float* next_row = rr + 1 < nrows ? row + row_stride : nullptr;
     const bool in_box_row = STATS && y >= box.hl && y < box.hu;
-    cfloat X[4][KEEP];
-    wf_row<KEEP, STATS, N1LO, N1HI>(row, mrow, t, L, slab, g, box, in_box_row, mean, rstd, tw_row, st_s,
-                                    st_q, X);
+    wf2 X[4][KEEP];
+    wf_row<KEEP, STATS, N1LO, N1HI, CLAMP_ALL, WF_PREFETCH>(px, mk, row, mrow, next_row, mrow + g.W, t,
+                                                            slab, twA, twB, twK, g, box.wl >> 8,
+                                                            in_box_row ? (box.wu >> 8) : 0, mean, rstd,
+                                                            st_s, st_q, X);
     if (rr & 1) {
+      int ts = t;
+      wf_pin(ts, X[0][0].x);  // store addresses: computed here, not carried across rows
+      const WfLane L = wf_lane(ts);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -770,6 +863,7 @@ static int geom_from(const mc_xc_geom* q, XcGeom* g, bool rows_pow2 = true, bool
 // mc_xc_row_engine(): 0 = automatic (wave-per-row kernel whenever the shape fits),
 // 1 = always the workgroup-per-row kernels (A/B timing and cross-checks of the engines).
 static int g_row_engine = 0;
+static int g_wave_prefetch = -1;  // tuning hook (mc_xc_row_engine(2 + depth)); -1 = default
 static bool mc_force_wg_rows() { return g_row_engine == 1; }
 
 // The wave-per-row kernel reads samples and mask rows with 16-byte loads.  job_off[] lives
@@ -788,8 +882,9 @@ static size_t rows_lds_bytes(int N, const XcGeom& g) {
 extern "C" {
 
 int mc_xc_row_engine(int mode) {
-  if (mode < 0 || mode > 1) return MC_ERR_ARG;
-  g_row_engine = mode;
+  if (mode < 0 || mode > 4) return MC_ERR_ARG;
+  g_row_engine = mode == 1 ? 1 : 0;
+  g_wave_prefetch = mode >= 2 ? mode - 2 : -1;
   return MC_OK;
 }
 
@@ -811,19 +906,28 @@ static int rows_forward_impl(const float* src, const int64_t* job_off, int64_t r
   const int logn = mc_ilog2(g.W) - 1;
   XcBox b = box ? *box : XcBox{0, 0, 0, 0};
   if (g.W == 2 * WF_N && g.nkx <= 512 && (g.ny % 8) == 0 && mask && !job_expo &&
-      wave_rows_aligned(src, mask, row_stride) &&
+      wave_rows_aligned(src, mask, row_stride) && (!stats_acc || ((b.wl | b.wu) & 255) == 0) &&
       !mc_force_wg_rows()) {
     // wave-per-row engine (mc_wave_fft.h); misaligned jobs take its element-wise loads
-    dim3 grid(njobs, (g.ny + 15) / 16);
-#define MC_WAVE_LAUNCH(KEEP, ST, LO, HI)                                                          \
-  hipLaunchKernelGGL((xc_rows_fwd_wave<KEEP, ST, LO, HI>), grid, dim3(256), 0, (hipStream_t)stream, \
-                     src, job_off, row_stride, mask, mean_rstd, (cfloat*)T1,                        \
+    dim3 grid(njobs, (g.ny + WF_ROWS_PER_WG - 1) / WF_ROWS_PER_WG);
+#define MC_WAVE_LAUNCH(KEEP, ST, LO, HI, CL, PF)                                                  \
+  hipLaunchKernelGGL((xc_rows_fwd_wave<KEEP, ST, LO, HI, CL, PF>), grid, dim3(256), 0,              \
+                     (hipStream_t)stream, src, job_off, row_stride, mask, mean_rstd, (cfloat*)T1,   \
                      (const cfloat*)tw_row, g, b, stats_acc)
-#define MC_WAVE_PICK(KEEP, ST)                                          \
-  do {                                                                  \
-    if (g.x0 >= 256 && g.x1 <= 3840) MC_WAVE_LAUNCH(KEEP, ST, 1, 15);   \
-    else MC_WAVE_LAUNCH(KEEP, ST, 0, 16);                               \
+#define MC_WAVE_PICK(KEEP, ST)                                                              \
+  do {                                                                                      \
+    if (g.x0 >= 256 && g.x0 <= 512 && g.x1 >= 3584 && g.x1 <= 3840)                         \
+      MC_WAVE_LAUNCH(KEEP, ST, 1, 15, false, WF_PREFETCH_DEFAULT); /* square 4096 frames */ \
+    else                                                                                    \
+      MC_WAVE_LAUNCH(KEEP, ST, 0, 16, true, WF_PREFETCH_DEFAULT);                           \
   } while (0)
+    if (g_wave_prefetch >= 0 && g.nkx > 256 && stats_acc && g.x0 >= 256 && g.x0 <= 512 && g.x1 >= 3584 &&
+        g.x1 <= 3840) {  // tuning hook: prefetch depth of the benchmark variant
+      if (g_wave_prefetch == 0) MC_WAVE_LAUNCH(2, true, 1, 15, false, 0);
+      else if (g_wave_prefetch == 1) MC_WAVE_LAUNCH(2, true, 1, 15, false, 1);
+      else MC_WAVE_LAUNCH(2, true, 1, 15, false, 2);
+      return mc_check_launch();
+    }
     if (g.nkx <= 256) {
       if (stats_acc) MC_WAVE_PICK(1, true); else MC_WAVE_PICK(1, false);
     } else {
