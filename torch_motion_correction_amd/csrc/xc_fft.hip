@@ -210,12 +210,11 @@ __device__ __forceinline__ void wf_load_px(const float* __restrict__ row, int t,
 #pragma unroll
   for (int n1 = N1LO; n1 < N1HI; ++n1) {
     const int x = 256 * n1 + 4 * t;
-    if (CLAMP_ALL || n1 == N1LO || n1 == N1HI - 1) {
-      const int xs = min(max(x, xlo), xhi);
-      px[n1] = *reinterpret_cast<const float4*>(row + xs);
-    } else {
-      px[n1] = *reinterpret_cast<const float4*>(row + x);
-    }
+    // read-once stream: non-temporal, so that it does not push the mask rows out of L2
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int xs = (CLAMP_ALL || n1 == N1LO || n1 == N1HI - 1) ? min(max(x, xlo), xhi) : x;
+    const f4 q = __builtin_nontemporal_load(reinterpret_cast<const f4*>(row + xs));
+    px[n1] = make_float4(q.x, q.y, q.z, q.w);
   }
 }
 
@@ -394,42 +393,58 @@ __global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
   const float* base = src + job_off[job];
   float st_s = 0.f, st_q = 0.f;
   cfloat* out = T1 + (int64_t)job * g.nkx * g.ny;
-  const int r_first = grp * WF_ROWS_PER_WG + wv * (WF_ROWS_PER_WG / 4);
-  int nrows = g.ny - r_first;  // ny % 8 == 0: a pair is in or out as a whole
-  nrows = nrows < 0 ? 0 : (nrows > WF_ROWS_PER_WG / 4 ? WF_ROWS_PER_WG / 4 : nrows);
+  // A workgroup takes 16 rows in two rounds of 8 consecutive rows; in a round wave wv
+  // transforms rows 2 wv and 2 wv + 1, parks their bins in its own slab as [kx][2 rows] and
+  // the workgroup then writes T1[job][kx][8 rows] as whole 64-byte pieces (every byte of T1
+  // written once; scattered 16-byte stores cost 2.8x the bytes at the memory side).
+  const int r16 = grp * WF_ROWS_PER_WG;
+  auto row_of = [&](int i) { return r16 + (i >> 1) * 8 + 2 * wv + (i & 1); };  // i = 0..3
+  const int nrows = g.ny - r16 >= 16 ? 4 : (g.ny - r16 >= 8 ? 2 : 0);  // ny % 8 == 0
   float4 px[16], mk[16];
   if (WF_PREFETCH >= 1 && nrows > 0)
-    wf_load_px<N1LO, N1HI, CLAMP_ALL>(base + (int64_t)(g.y0 + r_first) * row_stride, t, g, px);
+    wf_load_px<N1LO, N1HI, CLAMP_ALL>(base + (int64_t)(g.y0 + row_of(0)) * row_stride, t, g, px);
   if (WF_PREFETCH >= 2 && nrows > 0)
-    wf_load_mask<N1LO, N1HI>(mask + (int64_t)(g.y0 + r_first) * g.W, t, mk);
+    wf_load_mask<N1LO, N1HI>(mask + (int64_t)(g.y0 + row_of(0)) * g.W, t, mk);
   __syncthreads();
   wf2 Xe[4][KEEP];  // bins of the even row of the current pair
 #pragma unroll 1
   for (int rr = 0; rr < nrows; ++rr) {
-    const int r = r_first + rr;
-    const int y = g.y0 + r;
+    const int y = g.y0 + row_of(rr);
     const float* row = base + (int64_t)y * row_stride;
     const float* mrow = mask + (int64_t)y * g.W;
-    const float* next_row = rr + 1 < nrows ? row + row_stride : nullptr;
+    const int yn = g.y0 + row_of(rr + 1);
+    const float* next_row = rr + 1 < nrows ? base + (int64_t)yn * row_stride : nullptr;
+    const float* next_mrow = mask + (int64_t)yn * g.W;
     const bool in_box_row = STATS && y >= box.hl && y < box.hu;
     wf2 X[4][KEEP];
-    wf_row<KEEP, STATS, N1LO, N1HI, CLAMP_ALL, WF_PREFETCH>(px, mk, row, mrow, next_row, mrow + g.W, t,
+    wf_row<KEEP, STATS, N1LO, N1HI, CLAMP_ALL, WF_PREFETCH>(px, mk, row, mrow, next_row, next_mrow, t,
                                                             slab, twA, twB, twK, g, box.wl >> 8,
                                                             in_box_row ? (box.wu >> 8) : 0, mean, rstd,
                                                             st_s, st_q, X);
     if (rr & 1) {
       int ts = t;
-      wf_pin(ts, X[0][0].x);  // store addresses: computed here, not carried across rows
+      wf_pin(ts, X[0][0].x);  // addresses: computed here, not carried across rows
       const WfLane L = wf_lane(ts);
+      float4* park = reinterpret_cast<float4*>(slab);  // [kx] = {even row, odd row}; 410 x 16 B <= 8 KiB
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int k3 = 0; k3 < KEEP; ++k3) {
           const int k = L.kbin[s] + 256 * k3;
-          if (k < g.nkx)
-            *reinterpret_cast<float4*>(out + (int64_t)k * g.ny + (r - 1)) =
-                make_float4(Xe[s][k3].x, Xe[s][k3].y, X[s][k3].x, X[s][k3].y);
+          if (k < g.nkx) park[k] = make_float4(Xe[s][k3].x, Xe[s][k3].y, X[s][k3].x, X[s][k3].y);
         }
+      __syncthreads();
+      {
+        int tj = threadIdx.x;
+        wf_pin(tj, X[0][0].y);
+        const int r8 = r16 + (rr >> 1) * 8;
+        const float4* parked = reinterpret_cast<const float4*>(&slabs[0][0]);
+        for (int j = tj; j < 4 * g.nkx; j += 256) {  // 4 lanes = the 64 bytes of one kx
+          const int kx = j >> 2, w = j & 3;
+          *reinterpret_cast<float4*>(out + (int64_t)kx * g.ny + r8 + 2 * w) = parked[w * (WF_SLAB / 2) + kx];
+        }
+      }
+      __syncthreads();
     } else {
 #pragma unroll
       for (int s = 0; s < 4; ++s)
@@ -863,6 +878,7 @@ static int geom_from(const mc_xc_geom* q, XcGeom* g, bool rows_pow2 = true, bool
 // mc_xc_row_engine(): 0 = automatic (wave-per-row kernel whenever the shape fits),
 // 1 = always the workgroup-per-row kernels (A/B timing and cross-checks of the engines).
 static int g_row_engine = 0;
+static int g_wave_extra_lds = 0;  // tuning hook: dynamic LDS padding to cap workgroups per CU
 static int g_wave_prefetch = -1;  // tuning hook (mc_xc_row_engine(2 + depth)); -1 = default
 static bool mc_force_wg_rows() { return g_row_engine == 1; }
 
@@ -882,6 +898,10 @@ static size_t rows_lds_bytes(int N, const XcGeom& g) {
 extern "C" {
 
 int mc_xc_row_engine(int mode) {
+  if (mode >= 100) {  // tuning hook: 100 + KiB of dynamic LDS padding for the wave kernel
+    g_wave_extra_lds = (mode - 100) * 1024;
+    return MC_OK;
+  }
   if (mode < 0 || mode > 4) return MC_ERR_ARG;
   g_row_engine = mode == 1 ? 1 : 0;
   g_wave_prefetch = mode >= 2 ? mode - 2 : -1;
@@ -911,7 +931,7 @@ static int rows_forward_impl(const float* src, const int64_t* job_off, int64_t r
     // wave-per-row engine (mc_wave_fft.h); misaligned jobs take its element-wise loads
     dim3 grid(njobs, (g.ny + WF_ROWS_PER_WG - 1) / WF_ROWS_PER_WG);
 #define MC_WAVE_LAUNCH(KEEP, ST, LO, HI, CL, PF)                                                  \
-  hipLaunchKernelGGL((xc_rows_fwd_wave<KEEP, ST, LO, HI, CL, PF>), grid, dim3(256), 0,              \
+  hipLaunchKernelGGL((xc_rows_fwd_wave<KEEP, ST, LO, HI, CL, PF>), grid, dim3(256), g_wave_extra_lds,            \
                      (hipStream_t)stream, src, job_off, row_stride, mask, mean_rstd, (cfloat*)T1,   \
                      (const cfloat*)tw_row, g, b, stats_acc)
 #define MC_WAVE_PICK(KEEP, ST)                                                              \
