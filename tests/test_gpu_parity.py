@@ -576,3 +576,40 @@ def test_wave_row_engine_matches_workgroup_engine(dev, h):
     std, mean = torch.std_mean(img[:, hl:hu, wl:wu].double())
     assert float(res[0][1][0]) == pytest.approx(float(mean), rel=1e-6)
     assert float(res[0][1][2]) == pytest.approx(float(std), rel=1e-5)
+
+
+# ------------------------------------------------------------------ movie pipeline
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_movie_pipeline_equals_sequential_calls(mc, dev, overlap):
+    """motion_correct_movies (two-stream pipeline) returns, movie by movie, exactly what
+    estimate_global_motion followed by motion_correct_sum returns, and matches the oracle."""
+    movies, truth = [], []
+    for i, (t, n) in enumerate([(6, 512), (5, 256), (8, 512), (6, 512)]):
+        st, dy, dx = drift_stack(t, n, n, seed=100 + i)
+        movies.append((st * (1.0 + i) + 3.0 * i).to(dev))
+        truth.append((dy - dy[t // 2], dx - dx[t // 2]))
+    res = mc.motion_correct_movies(movies, 1.0, return_frames=True, overlap=overlap)
+    torch.cuda.synchronize()
+    assert len(res) == len(movies)
+    for m, r, (ty, tx) in zip(movies, res, truth):
+        field = mc.estimate_global_motion(m, 1.0)
+        total, frames = mc.motion_correct_sum(m, field, 1.0, return_frames=True)
+        assert torch.equal(r.field, field)
+        assert torch.equal(r.total, total) and torch.equal(r.frames, frames)
+        assert r.field[0, :, 0, 0].cpu().tolist() == [float(v) for v in ty]
+        assert r.field[1, :, 0, 0].cpu().tolist() == [float(v) for v in tx]
+    o = oracle.estimate_global_motion(movies[0].cpu(), 1.0)
+    assert torch.equal(res[0].field.cpu(), o)
+    # sum-only mode, and the generator form used by bench.py
+    only = mc.motion_correct_movies(movies[:2], 1.0, overlap=overlap)
+    assert only[0].frames is None and torch.equal(only[1].total, res[1].total)
+    pipe = mc.MoviePipeline(dev, 1.0, return_frames=False, overlap=overlap)
+    last = None
+    for last in pipe.iterate([movies[2]] * 3):
+        pass
+    torch.cuda.synchronize()
+    assert torch.equal(last.total, res[2].total)
+    with pytest.raises(ValueError):
+        mc.motion_correct_movies([movies[0][0]], 1.0)

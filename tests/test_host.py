@@ -275,3 +275,13 @@ def test_leave_one_out_schedule_replays_the_table(t):
         assert running == {o for o in range(t) if o != f and ref_expo[f, o] == 1}
     if t <= 50:
         assert int(rebuild.sum()) == 1  # only frame 0; afterwards one frame joins per step
+
+
+def test_movie_pipeline_needs_a_gpu_and_is_exported():
+    """No CPU fallback for the batch entry point either."""
+    import torch_motion_correction_amd as m
+
+    assert {"motion_correct_movies", "MoviePipeline", "MovieResult"} <= set(m.__all__)
+    if not torch.cuda.is_available():
+        with pytest.raises(m.McorrError):
+            m.motion_correct_movies([torch.zeros(2, 64, 64)], 1.0)

@@ -17,6 +17,7 @@ from .api import (  # noqa: F401
     resample_deformation_field,
 )
 from ._lib import McorrError  # noqa: F401
+from .pipeline import MoviePipeline, MovieResult, motion_correct_movies  # noqa: F401
 
 __all__ = [
     "correct_motion",
@@ -31,5 +32,8 @@ __all__ = [
     "resample_deformation_field",
     "image_shifts_to_deformation_field",
     "McorrError",
+    "motion_correct_movies",
+    "MoviePipeline",
+    "MovieResult",
 ]
 __version__ = "0.1.0"

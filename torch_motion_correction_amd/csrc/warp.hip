@@ -358,14 +358,17 @@ __global__ void rigid_base(const float* __restrict__ shifts, int nframes, int h,
   const int f = blockIdx.y, axis = blockIdx.z;
   const int n = axis == 0 ? h : w;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  const float s = shifts[2 * f + axis];
-  const float u = grid_chain((float)p + s, (float)n);
-  const float d = floorf(u) - (float)p;
-  // clamp the (finite) offset so absurd shifts cannot overflow
-  const float lim = 3.0f * (float)n + 16.f;
-  const int di = (int)fminf(fmaxf(d, -lim), lim);
-  atomicMin(&S[2 * f + axis], di);
+  int di = 0x7fffffff;
+  if (p < n) {
+    const float s = shifts[2 * f + axis];
+    const float u = grid_chain((float)p + s, (float)n);
+    const float d = floorf(u) - (float)p;
+    // clamp the (finite) offset so absurd shifts cannot overflow
+    const float lim = 3.0f * (float)n + 16.f;
+    di = (int)fminf(fmaxf(d, -lim), lim);
+  }
+  for (int off = 32; off > 0; off >>= 1) di = min(di, __shfl_xor(di, off));  // one atomic per wave
+  if ((threadIdx.x & 63) == 0 && di != 0x7fffffff) atomicMin(&S[2 * f + axis], di);
 }
 
 // pass 1: W[f][axis][k][p], k = 0..4

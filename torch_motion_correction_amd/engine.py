@@ -181,10 +181,10 @@ def _global_spectra(img, pl):
     st = stream_ptr(dev)
     mhat = mask_spectrum(pl, dev)
     # provisional mean m0 keeps the linear fix-up free of cancellation; any value near the
-    # true mean does, so a few rows of frame 0's box are enough (one small workgroup)
+    # true mean does, so one row of frame 0's box is enough (one small workgroup)
     acc = torch.empty(128, dtype=torch.float64, device=dev)  # 64 x {sum, sumsq}
     m0 = torch.ones(3, dtype=torch.float32, device=dev)
-    check(lib.mc_central_box_stats(ptr(img), 1, h, w, hl, min(hu, hl + 8), wl, wu, ptr(acc), ptr(m0), st),
+    check(lib.mc_central_box_stats(ptr(img), 1, h, w, hl, hl + 1, wl, wu, ptr(acc), ptr(m0), st),
           "mc_central_box_stats")
     m0[1:].fill_(1.0)
     fix = torch.empty(2, dtype=torch.float32, device=dev)
