@@ -613,3 +613,30 @@ def test_movie_pipeline_equals_sequential_calls(mc, dev, overlap):
     assert torch.equal(last.total, res[2].total)
     with pytest.raises(ValueError):
         mc.motion_correct_movies([movies[0][0]], 1.0)
+
+
+# ------------------------------------------------------------------ near-window search + fallback
+
+
+def test_near_window_search_and_device_side_fallback(mc, dev):
+    """H >= 1024 goes through mc_xc_correlate_argmax: near-window rows first, the full map
+    only when a far row can still win.  (i) small drift: settled in the near window;
+    (ii) shifts of several hundred pixels: the gated full pass must find them;
+    (iii) pure noise: nothing can be skipped, the arg-max must still be the oracle's."""
+    n = 1024
+    g = torch.Generator().manual_seed(31)
+    base = torch.randn(n + 1024, n + 1024, generator=g)
+    offs = [(0, 0), (3, -5), (300, -210), (-410, 95), (60, 500), (-64, -65)]
+    st = torch.stack([base[512 - dy : 512 - dy + n, 512 - dx : 512 - dx + n] + 0.5 * torch.randn(n, n, generator=g)
+                      for dy, dx in offs])
+    got = mc.estimate_global_motion(st.to(dev), 1.0, reference_frame=0).cpu()
+    assert got[0, :, 0, 0].tolist() == [float(o[0]) for o in offs]
+    assert got[1, :, 0, 0].tolist() == [float(o[1]) for o in offs]
+    assert torch.equal(got, oracle.estimate_global_motion(st, 1.0, reference_frame=0))
+    noise = torch.randn(3, n, n, generator=g)
+    gotn = mc.estimate_global_motion(noise.to(dev), 1.0).cpu()
+    refn, ccs = oracle.estimate_global_motion(noise, 1.0, return_cc=True)
+    for f, cc in ccs.items():  # compare where the oracle's own maximum is not a near-tie
+        top = torch.topk(cc.flatten(), 2).values
+        if float(top[0] - top[1]) > 1e-4 * float(top[0].abs()):
+            assert torch.equal(gotn[:, f], refn[:, f])

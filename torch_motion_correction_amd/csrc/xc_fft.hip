@@ -36,6 +36,8 @@ struct XcGeom {
 // Two LDS lines (ping-pong: one barrier per pass), twiddles in registers for the whole
 // row loop, and the next row's samples + mask values already in flight (registers)
 // while the current row is transformed.
+__device__ __forceinline__ int kept_index(int ky, int H, int kyp, int kyn);
+
 struct XcBox {  // central box of normalize_image (utils.py:76-81) in window coordinates
   int hl, hu, wl, wu;
 };
@@ -546,9 +548,10 @@ __global__ __launch_bounds__(MC_WG) void xc_cols_inv(
     const cfloat* __restrict__ S_cur, const int* __restrict__ cur_idx,
     const cfloat* __restrict__ S_ref, const int* __restrict__ ref_idx,
     const float* __restrict__ shifts, cfloat* __restrict__ T2, const cfloat* __restrict__ tw_col,
-    float scale, XcGeom g) {
+    float scale, XcGeom g, const int* __restrict__ gate) {
   constexpr int H = 1 << LOGH;
   __shared__ __attribute__((aligned(16))) cfloat line[lds_len(H)];
+  if (gate && gate[0] == 0) return;  // the near window settled every pair: nothing to do
   const int tid = threadIdx.x;
   const int kx = blockIdx.x, p = blockIdx.y;
   const int nky = g.kyp + g.kyn;
@@ -583,6 +586,76 @@ __global__ __launch_bounds__(MC_WG) void xc_cols_inv(
   };
   auto store = [&](int y, cfloat v) { out[y] = v; };
   wg_fft<H, +1>(line, tid, tw_col, 1, load, store);
+}
+
+// K3 for the arg-max search without the full T2: a workgroup runs XC_NEAR_COLS columns of
+// one pair through the inverse column FFT, keeps only the rows of the near window
+// (|shift_y| < nnear: rows [0, nnear) and [H - nnear, H)) in T2n[p][kx][2 nnear] and adds
+// its share of the triangle-inequality row bounds (see K4) to bounds[p][y] -- per thread in
+// registers over its columns, then one float atomic per (thread, row).  The full map is
+// only ever materialised (xc_cols_inv, gated by `need_full`) when some far row's bound
+// reaches the maximum found in the near window.
+#define XC_NEAR_COLS 8
+template <int LOGH>
+__global__ __launch_bounds__(MC_WG) void xc_cols_inv_near(
+    const cfloat* __restrict__ S_cur, const int* __restrict__ cur_idx,
+    const cfloat* __restrict__ S_ref, const int* __restrict__ ref_idx, cfloat* __restrict__ T2n,
+    float* __restrict__ bounds, const cfloat* __restrict__ tw_col, float scale, XcGeom g, int nnear) {
+  constexpr int H = 1 << LOGH;
+  __shared__ __attribute__((aligned(16))) cfloat line[lds_len(H)];
+  __shared__ float bl[H];  // this workgroup's share of the row bounds
+  const int tid = threadIdx.x;
+  const int p = blockIdx.y;
+  const int nky = g.kyp + g.kyn;
+  for (int y = tid; y < H; y += MC_WG) bl[y] = 0.f;
+  // (the last pass of every column hands a thread the same rows y, so bl[y] has one owner;
+  // the barrier inside the first transform orders the zeroing before any use)
+#pragma unroll 1
+  for (int cc = 0; cc < XC_NEAR_COLS; ++cc) {
+    const int kx = blockIdx.x * XC_NEAR_COLS + cc;
+    if (kx >= g.nkx) break;  // workgroup-uniform
+    const cfloat* cur = S_cur + ((int64_t)cur_idx[p] * g.nkx + kx) * nky;
+    const cfloat* ref = S_ref + ((int64_t)ref_idx[p] * g.nkx + kx) * nky;
+    cfloat* outn = T2n + ((int64_t)p * g.nkx + kx) * (2 * nnear);
+    const float wgt = kx == 0 ? 1.f : 2.f;
+    auto load = [&](int ky) {
+      const int kyi = kept_index(ky, H, g.kyp, g.kyn);
+      if (kyi < 0) return cmake(0.f, 0.f);
+      return cscale(cmulc(ref[kyi], cur[kyi]), scale);
+    };
+    auto store = [&](int y, cfloat v) {
+      const int yn = y < nnear ? y : y - (H - 2 * nnear);  // position in the near window
+      if (yn >= 0 && yn < 2 * nnear && (y < nnear || y >= H - nnear)) outn[yn] = v;
+      // hardware square root (1 ulp): the bound test carries a 1e-4 relative slack
+      bl[y] += wgt * __builtin_amdgcn_sqrtf(v.x * v.x + v.y * v.y);
+    };
+    // opaque per column: the twiddle powers of every pass are loop-invariant and would
+    // otherwise be hoisted out of the column loop into ~90 registers (one workgroup less per CU)
+    const cfloat* twp = tw_col;
+    asm volatile("" : "+s"(twp));
+    wg_fft<H, +1>(line, tid, twp, 1, load, store);
+    __syncthreads();  // the next column's first pass overwrites the line
+  }
+  for (int y = tid; y < H; y += MC_WG) atomicAdd(&bounds[(int64_t)p * H + y], bl[y]);
+}
+
+// After the near-window phase: a far row group must be evaluated iff its bound can reach
+// the maximum attained so far.  Initialises the far groups' candidates and raises
+// need_full[0] when any such group exists.
+__global__ void xc_far_needed(const float* __restrict__ bounds, const int* __restrict__ best,
+                              float* __restrict__ part_val, int* __restrict__ part_idx,
+                              int* __restrict__ need_full, int H, int RG, int near) {
+  const int ngrp = H / RG;
+  const int p = blockIdx.y;
+  const int grp = near + blockIdx.x * blockDim.x + threadIdx.x;
+  if (grp >= ngrp - near) return;
+  float b = 0.f;
+  for (int r = 0; r < RG; ++r) b = fmaxf(b, bounds[(int64_t)p * H + grp * RG + r]);
+  b = b * 1.0001f + 1e-30f;
+  part_val[(int64_t)p * ngrp + grp] = -INFINITY;
+  part_idx[(int64_t)p * ngrp + grp] = 0x7fffffff;
+  const int fb = __float_as_int(b);
+  if ((fb >= 0 ? fb : fb ^ 0x7fffffff) >= best[p]) atomicOr(need_full, 1);
 }
 
 // ------------------------------------------------------------------ K4: rows inverse
@@ -650,8 +723,10 @@ __global__ __launch_bounds__(MC_WG) void xc_rows_inv(const cfloat* __restrict__ 
                                                      const int64_t* __restrict__ out_off,
                                                      int64_t out_stride,
                                                      const cfloat* __restrict__ tw_row, XcGeom g,
-                                                     int near, int phase) {
+                                                     int near, int phase, int compact,
+                                                     const int* __restrict__ gate) {
   constexpr int N = 1 << LOGN;
+  if (gate && gate[0] == 0) return;  // far phase not needed (xc_far_needed filled the candidates)
   constexpr int NT = fft_threads(N), SG = MC_WG / NT;
   constexpr int R0 = FftPlan<N>::radix(0), NB0 = N / R0, IT0 = (NB0 + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -682,10 +757,12 @@ __global__ __launch_bounds__(MC_WG) void xc_rows_inv(const cfloat* __restrict__ 
       }
     }
   }
-  const cfloat* in = T2 + (int64_t)p * g.nkx * g.H + (int64_t)grp * RG;
+  // compact: T2 holds only the near window, [p][kx][2 near RG] (xc_cols_inv_near)
+  const int cstride = compact ? 2 * near * RG : g.H;
+  const cfloat* in = T2 + (int64_t)p * g.nkx * cstride + (int64_t)(compact ? (int)blockIdx.x : grp) * RG;
   for (int i = tid; i < g.nkx * RG; i += MC_WG) {
     const int kx = i / RG, r = i - kx * RG;
-    stg[kx * (RG + 1) + r] = in[(int64_t)kx * g.H + r];
+    stg[kx * (RG + 1) + r] = in[(int64_t)kx * cstride + r];
   }
   FftTwiddles<N> T;
   T.template init<+1>(lt, tw_row, 2);
@@ -1030,7 +1107,8 @@ int mc_xc_cols_inverse(const void* S_cur, const int* cur_idx, const void* S_ref,
   MC_DISPATCH_LOG(mc_ilog2(g.H), {
     hipLaunchKernelGGL((xc_cols_inv<L, 0>), grid, dim3(MC_WG), 0, (hipStream_t)stream,
                        (const cfloat*)S_cur, cur_idx, (const cfloat*)S_ref, ref_idx,
-                       (const float*)nullptr, (cfloat*)T2, (const cfloat*)tw_col, scale, g);
+                       (const float*)nullptr, (cfloat*)T2, (const cfloat*)tw_col, scale, g,
+                       (const int*)nullptr);
   });
   return mc_check_launch();
 }
@@ -1046,7 +1124,7 @@ int mc_fourier_shift_cols_inverse(const void* S, const int* idx, const float* sh
   MC_DISPATCH_LOG(mc_ilog2(g.H), {
     hipLaunchKernelGGL((xc_cols_inv<L, 1>), grid, dim3(MC_WG), 0, (hipStream_t)stream,
                        (const cfloat*)S, idx, (const cfloat*)nullptr, (const int*)nullptr, shifts,
-                       (cfloat*)T2, (const cfloat*)tw_col, scale, g);
+                       (cfloat*)T2, (const cfloat*)tw_col, scale, g, (const int*)nullptr);
   });
   return mc_check_launch();
 }
@@ -1086,16 +1164,109 @@ int mc_xc_rows_inverse_argmax(const void* T2, float* part_val, int* part_idx, in
     if (near > 0)
       hipLaunchKernelGGL(k, dim3(2 * near, npairs), dim3(MC_WG), lds, (hipStream_t)stream,
                          (const cfloat*)T2, (const float*)bounds, best, part_val, part_idx, (float*)nullptr,
-                         (const int64_t*)nullptr, (int64_t)0, (const cfloat*)tw_row, g, near, 0);
+                         (const int64_t*)nullptr, (int64_t)0, (const cfloat*)tw_row, g, near, 0, 0,
+                         (const int*)nullptr);
     if (ngrp - 2 * near > 0)
       hipLaunchKernelGGL(k, dim3(ngrp - 2 * near, npairs), dim3(MC_WG), lds, (hipStream_t)stream,
                          (const cfloat*)T2, (const float*)bounds, best, part_val, part_idx, (float*)nullptr,
-                         (const int64_t*)nullptr, (int64_t)0, (const cfloat*)tw_row, g, near, 1);
+                         (const int64_t*)nullptr, (int64_t)0, (const cfloat*)tw_row, g, near, 1, 0,
+                         (const int*)nullptr);
   });
   rc = mc_check_launch();
   if (rc) return rc;
   hipLaunchKernelGGL(xc_peak_final, dim3(npairs), dim3(64), 0, (hipStream_t)stream, part_val,
                      part_idx, ngrp, g.H, g.W, peaks, shifts);
+  return mc_check_launch();
+}
+
+int mc_xc_near_rows(const mc_xc_geom* q) {
+  XcGeom g;
+  int rc = geom_from(q, &g, true, true);
+  if (rc) return rc;
+  int near = (64 + g.RG - 1) / g.RG;
+  if (2 * near > g.H / g.RG) near = (g.H / g.RG) / 2;
+  return near * g.RG;
+}
+
+int mc_xc_correlate_argmax(const void* S_cur, const int* cur_idx, const void* S_ref,
+                           const int* ref_idx, void* T2_full, void* T2_near, float* part_val,
+                           int* part_idx, int* peaks, float* shifts, const void* tw_col,
+                           const void* tw_row, float scale, int npairs, const mc_xc_geom* q,
+                           void* stream) {
+  XcGeom g;
+  int rc = geom_from(q, &g, true, true);
+  if (rc) return rc;
+  if (!S_cur || !cur_idx || !S_ref || !ref_idx || !T2_full || !T2_near || !part_val || !part_idx ||
+      !peaks || !shifts || !tw_col || !tw_row || npairs < 1)
+    return MC_ERR_ARG;
+  if (g.H < 1024) return MC_ERR_UNSUPPORTED;  // every thread must own H / 256 outputs of the last pass
+  hipStream_t st = (hipStream_t)stream;
+  const int logn = mc_ilog2(g.W) - 1;
+  const size_t lds = rows_lds_bytes(g.W / 2, g);
+  if (lds > 160 * 1024) return MC_ERR_ARG;
+  const int ngrp = g.H / g.RG;
+  int near = (64 + g.RG - 1) / g.RG;
+  if (2 * near > ngrp) near = ngrp / 2;
+  if (near < 1) return MC_ERR_UNSUPPORTED;
+  const int nnear = near * g.RG;
+  int* best = part_idx + (int64_t)npairs * ngrp;  // npairs running maxima, then the gate word
+  int* gate = best + npairs;
+  float* bounds = part_val + (int64_t)npairs * ngrp;  // npairs * H row bounds
+  {
+    const float ninf = -INFINITY;
+    int pat;
+    memcpy(&pat, &ninf, 4);
+    pat = pat >= 0 ? pat : pat ^ 0x7fffffff;
+    hipError_t e = hipMemsetD32Async((hipDeviceptr_t)best, pat, npairs, st);
+    if (e == hipSuccess) e = hipMemsetAsync(gate, 0, sizeof(int), st);
+    if (e == hipSuccess) e = hipMemsetAsync(bounds, 0, sizeof(float) * (size_t)npairs * g.H, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  MC_DISPATCH_LOG(mc_ilog2(g.H), {
+    if constexpr (L >= 10) {
+      hipLaunchKernelGGL(xc_cols_inv_near<L>, dim3((g.nkx + XC_NEAR_COLS - 1) / XC_NEAR_COLS, npairs),
+                         dim3(MC_WG), 0, st, (const cfloat*)S_cur, cur_idx, (const cfloat*)S_ref, ref_idx,
+                         (cfloat*)T2_near, bounds, (const cfloat*)tw_col, scale, g, nnear);
+    } else {
+      return MC_ERR_UNSUPPORTED;
+    }
+  });
+  rc = mc_check_launch();
+  if (rc) return rc;
+  const int nfar = ngrp - 2 * near;
+  MC_DISPATCH_LOG(logn, {
+    auto k = xc_rows_inv<L, 0>;
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(2 * near, npairs), dim3(MC_WG), lds, st, (const cfloat*)T2_near,
+                       (const float*)bounds, best, part_val, part_idx, (float*)nullptr,
+                       (const int64_t*)nullptr, (int64_t)0, (const cfloat*)tw_row, g, near, 0, 1,
+                       (const int*)nullptr);
+  });
+  rc = mc_check_launch();
+  if (rc) return rc;
+  if (nfar > 0) {
+    hipLaunchKernelGGL(xc_far_needed, dim3((nfar + 63) / 64, npairs), dim3(64), 0, st,
+                       (const float*)bounds, (const int*)best, part_val, part_idx, gate, g.H, g.RG, near);
+    // fallback, skipped on the device unless a far row can still win: full map + far phase
+    MC_DISPATCH_LOG(mc_ilog2(g.H), {
+      hipLaunchKernelGGL((xc_cols_inv<L, 0>), dim3(g.nkx, npairs), dim3(MC_WG), 0, st,
+                         (const cfloat*)S_cur, cur_idx, (const cfloat*)S_ref, ref_idx,
+                         (const float*)nullptr, (cfloat*)T2_full, (const cfloat*)tw_col, scale, g,
+                         (const int*)gate);
+    });
+    MC_DISPATCH_LOG(logn, {
+      auto k = xc_rows_inv<L, 0>;
+      hipLaunchKernelGGL(k, dim3(nfar, npairs), dim3(MC_WG), lds, st, (const cfloat*)T2_full,
+                         (const float*)bounds, best, part_val, part_idx, (float*)nullptr,
+                         (const int64_t*)nullptr, (int64_t)0, (const cfloat*)tw_row, g, near, 1, 0,
+                         (const int*)gate);
+    });
+    rc = mc_check_launch();
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(xc_peak_final, dim3(npairs), dim3(64), 0, st, part_val, part_idx, ngrp, g.H, g.W,
+                     peaks, shifts);
   return mc_check_launch();
 }
 
@@ -1116,7 +1287,7 @@ int mc_xc_rows_inverse_store(const void* T2, float* out, const int64_t* out_off,
       (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, grid, dim3(MC_WG), lds, (hipStream_t)stream, (const cfloat*)T2,
                        (const float*)nullptr, (int*)nullptr, (float*)nullptr, (int*)nullptr, out, out_off, out_stride,
-                       (const cfloat*)tw_row, g, 0, 0);
+                       (const cfloat*)tw_row, g, 0, 0, 0, (const int*)nullptr);
   });
   return mc_check_launch();
 }

@@ -118,11 +118,22 @@ def _peaks(S_cur, cur_idx, S_ref, ref_idx, pl, want_nbhd):
     T2 = torch.empty((chunk, g.nkx, g.H, 2), dtype=torch.float32, device=dev)
     ngrp = g.H // g.RG
     pv = torch.empty(chunk * ngrp + chunk * g.H, dtype=torch.float32, device=dev)
-    pi = torch.empty(chunk * ngrp + chunk, dtype=torch.int32, device=dev)
+    pi = torch.empty(chunk * ngrp + chunk + 1, dtype=torch.int32, device=dev)
     st = stream_ptr(dev)
     scale = 1.0 / (g.H * g.W)
+    # arg-max only: near-window search, the full map (T2) is a device-side fallback that
+    # normally never runs (mc_xc_correlate_argmax)
+    fused = (not want_nbhd) and _pow2(g.W) and _pow2(g.H) and g.H >= 1024
+    if fused:
+        T2n = torch.empty((chunk, g.nkx, 2 * lib.mc_xc_near_rows(g), 2), dtype=torch.float32, device=dev)
     for a in range(0, npairs, chunk):
         n = min(chunk, npairs - a)
+        if fused:
+            check(lib.mc_xc_correlate_argmax(ptr(S_cur), ptr(cur_idx[a : a + n]), ptr(S_ref),
+                                             ptr(ref_idx[a : a + n]), ptr(T2), ptr(T2n), ptr(pv), ptr(pi),
+                                             ptr(peaks[a : a + n]), ptr(shifts[a : a + n]), ptr(pl.tw_col),
+                                             ptr(pl.tw_row), scale, n, g, st), "mc_xc_correlate_argmax")
+            continue
         if _pow2(g.H):
             check(lib.mc_xc_cols_inverse(ptr(S_cur), ptr(cur_idx[a : a + n]), ptr(S_ref),
                                          ptr(ref_idx[a : a + n]), ptr(T2), ptr(pl.tw_col), scale, n, g,
