@@ -129,6 +129,20 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # the same launch with the chip to itself (outside the timed region): under --overlap the
+    # timed launches share HBM with the next step's estimator, which stretches them
+    solo_ms = None
+    if not args.no_overlap:
+        lat = engine.frame_lattices(out.field.contiguous(), t, "catmull_rom")
+        ev = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            engine.warp(stack, lat, 1.0, want_frames=True, want_sum=True, rigid=True)
+            e1.record()
+            ev.append((e0, e1))
+        torch.cuda.synchronize()
+        solo_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
     shifts = (out.field[:, :, 0, 0].transpose(0, 1) / 1.0).cpu()
     shifts_ok = bool(torch.equal(shifts, expect))
     warp_ms = sum(a.elapsed_time(b) for a, b in warp_events) / max(len(warp_events), 1)
@@ -187,6 +201,11 @@ def main():
                 "bound": "hbm", "kernel": "warp_rigid_dma", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "ms_per_launch": warp_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                # extras: the kernel alone on the chip, and the whole step against SURVEY 8d's
+                # compulsory 12 B/pixel/frame (frame read by the estimator, read + written by the warp)
+                "ms_per_launch_unshared": solo_ms,
+                "frac_unshared": (alg_bytes / (solo_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if solo_ms else None,
+                "whole_step_frac": 12.0 * h * w * t / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
             },
             "cpu_baseline": cpu,
         }

@@ -603,13 +603,15 @@ __global__ __launch_bounds__(MC_WG) void xc_cols_inv_near(
     float* __restrict__ bounds, const cfloat* __restrict__ tw_col, float scale, XcGeom g, int nnear) {
   constexpr int H = 1 << LOGH;
   __shared__ __attribute__((aligned(16))) cfloat line[lds_len(H)];
-  __shared__ float bl[H];  // this workgroup's share of the row bounds
+  constexpr int NOUT = H / MC_WG;  // rows per thread in the last pass (H >= 1024: all threads busy)
   const int tid = threadIdx.x;
   const int p = blockIdx.y;
   const int nky = g.kyp + g.kyn;
-  for (int y = tid; y < H; y += MC_WG) bl[y] = 0.f;
-  // (the last pass of every column hands a thread the same rows y, so bl[y] has one owner;
-  // the barrier inside the first transform orders the zeroing before any use)
+  // this thread's share of the row bounds: the last pass of every column hands a thread the
+  // same NOUT rows in the same order, so the sums stay in registers over the column loop
+  float acc[NOUT];
+#pragma unroll
+  for (int c = 0; c < NOUT; ++c) acc[c] = 0.f;
 #pragma unroll 1
   for (int cc = 0; cc < XC_NEAR_COLS; ++cc) {
     const int kx = blockIdx.x * XC_NEAR_COLS + cc;
@@ -623,20 +625,33 @@ __global__ __launch_bounds__(MC_WG) void xc_cols_inv_near(
       if (kyi < 0) return cmake(0.f, 0.f);
       return cscale(cmulc(ref[kyi], cur[kyi]), scale);
     };
+    int c = 0;
     auto store = [&](int y, cfloat v) {
       const int yn = y < nnear ? y : y - (H - 2 * nnear);  // position in the near window
       if (yn >= 0 && yn < 2 * nnear && (y < nnear || y >= H - nnear)) outn[yn] = v;
       // hardware square root (1 ulp): the bound test carries a 1e-4 relative slack
-      bl[y] += wgt * __builtin_amdgcn_sqrtf(v.x * v.x + v.y * v.y);
+      acc[c++] += wgt * __builtin_amdgcn_sqrtf(v.x * v.x + v.y * v.y);
     };
-    // opaque per column: the twiddle powers of every pass are loop-invariant and would
-    // otherwise be hoisted out of the column loop into ~90 registers (one workgroup less per CU)
-    const cfloat* twp = tw_col;
-    asm volatile("" : "+s"(twp));
-    wg_fft<H, +1>(line, tid, twp, 1, load, store);
+    // opaque per column: everything derived from the thread index (kept-row indices, near
+    // positions, LDS addresses of every pass) is loop-invariant and would otherwise be
+    // hoisted out of the column loop into ~90 registers (one workgroup less per CU)
+    int tcol = tid;
+    asm volatile("" : "+v"(tcol));
+    wg_fft<H, +1>(line, tcol, tw_col, 1, load, store);
     __syncthreads();  // the next column's first pass overwrites the line
   }
-  for (int y = tid; y < H; y += MC_WG) atomicAdd(&bounds[(int64_t)p * H + y], bl[y]);
+  // rows of the last pass (fft_pass with NS * R == H): y = tid + it * MC_WG + m * (H / R), in
+  // the order it-major, m-minor
+  {
+    constexpr int R = (H >= 4096) ? 8 : (H == 2048 ? 4 : 2);  // last radix of FftPlan<H>: 8 8 8 {8,4,2}
+    constexpr int NB = H / R, IT = NB / MC_WG;
+    static_assert(IT * R == NOUT, "row ownership of the last pass");
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+#pragma unroll
+      for (int m = 0; m < R; ++m)
+        atomicAdd(&bounds[(int64_t)p * H + tid + it * MC_WG + m * NB], acc[it * R + m]);
+  }
 }
 
 // After the near-window phase: a far row group must be evaluated iff its bound can reach
