@@ -6,7 +6,7 @@ tag=${1:-traffic}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/${tag}_$c -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_$c.log 2>&1 || exit 1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/${tag}_$c -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-overlap > gpurun_out/${tag}_$c.log 2>&1 || exit 1
 done
 python3 - gpurun_out/${tag}_FETCH_SIZE gpurun_out/${tag}_WRITE_SIZE <<'PY'
 import csv, sys, glob, collections, json
@@ -27,7 +27,7 @@ for k, v in out.items():
 rows.sort(reverse=True)
 print(f"{'kernel':64s} {'calls':>5s} {'us(pmc)':>8s} {'readGB':>7s} {'writeGB':>7s} {'TB/s':>6s}")
 for _, k, n, us, rd, wr in rows[:14]:
-    print(f"{k:64s} {n:5d} {us:8.1f} {rd:7.3f} {wr:7.3f} {(rd + wr) / us * 1e-3 if us else 0:6.2f}")
+    print(f"{k:64s} {n:5d} {us:8.1f} {rd:7.3f} {wr:7.3f} {(rd + wr) / us * 1e3 if us else 0:6.2f}")
 json.dump([{"kernel": k, "calls": n, "us_under_pmc": us, "read_GB": rd, "write_GB": wr} for _, k, n, us, rd, wr in rows[:20]],
           open(sys.argv[1] + "/../" + sys.argv[1].split("/")[-1].replace("_FETCH_SIZE", "") + "_summary.json", "w"), indent=1)
 PY
