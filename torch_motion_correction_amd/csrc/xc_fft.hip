@@ -363,7 +363,14 @@ __global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
   const int t = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   wf2* slab = reinterpret_cast<wf2*>(slabs[wv]);
-  const int job = blockIdx.x, grp = blockIdx.y;
+  // Workgroup -> (job, row group): workgroups are dealt round-robin over the 8 XCDs (speed
+  // only, MI355X guide), so every job of one row group is sent to the same XCD: its L2 then
+  // fetches the group's mask rows once for all jobs instead of once per XCD.
+  const int njobs = gridDim.y;
+  const int b = blockIdx.x + gridDim.x * blockIdx.y;  // gridDim.x = 8 * ceil(groups / 8)... see host
+  const int grp = 8 * (b / (8 * njobs)) + (b & 7);
+  const int job = (b >> 3) % njobs;
+  if (grp * WF_ROWS_PER_WG >= g.ny) return;  // padding of the last eight groups (uniform)
   {  // tables from tw_row[k] = exp(-2 pi i k / 4096): W_2048^m = tw_row[2 m], W_128^m =
      // tw_row[32 m]; all loads issued before the first LDS write
     constexpr int NTAB = WF_TWA + WF_TWB + 256, PER = (NTAB + 255) / 256;
@@ -1021,7 +1028,8 @@ static int rows_forward_impl(const float* src, const int64_t* job_off, int64_t r
       wave_rows_aligned(src, mask, row_stride) && (!stats_acc || ((b.wl | b.wu) & 255) == 0) &&
       !mc_force_wg_rows()) {
     // wave-per-row engine (mc_wave_fft.h); misaligned jobs take its element-wise loads
-    dim3 grid(njobs, (g.ny + WF_ROWS_PER_WG - 1) / WF_ROWS_PER_WG);
+    const int ngroups = (g.ny + WF_ROWS_PER_WG - 1) / WF_ROWS_PER_WG;
+    dim3 grid((ngroups + 7) / 8 * 8, njobs);  // linear id = x + gridDim.x * y, decoded in the kernel
 #define MC_WAVE_LAUNCH(KEEP, ST, LO, HI, CL, PF)                                                  \
   hipLaunchKernelGGL((xc_rows_fwd_wave<KEEP, ST, LO, HI, CL, PF>), grid, dim3(256), g_wave_extra_lds,            \
                      (hipStream_t)stream, src, job_off, row_stride, mask, mean_rstd, (cfloat*)T1,   \
