@@ -71,6 +71,18 @@ int mc_xc_rows_forward(const float* src, const int64_t* job_off, int64_t row_str
                        const int* job_expo, const float* mask, const float* mean_rstd, void* T1,
                        const void* tw_row, int njobs, const mc_xc_geom* geom, void* stream);
 
+/* Dose-weighted accumulation in Fourier space (the caller-side exposure filter of the
+ * reference's pipeline, examples/ttMotion.py:331-351, crit_exposure_bfactor = -1):
+ * A[kx][ky] (+)= sum_j q_{frame0+j}(k) * S[j][kx][ky] over the nframes full spectra in S
+ * ([j][W/2+1][H] complex, as K1+K2 with the full geometry produce them); first != 0 starts A
+ * from zero, last != 0 applies 1/sqrt(sum over all total_frames of q^2).  An inverse
+ * transform of A (mc_fourier_shift_cols_inverse with zero shifts + mc_xc_rows_inverse_store)
+ * then gives sum_f irfft2(q_f * rfft2(frame_f)).  q_f = exp(-0.5 N_f / N_c(k)), Grant &
+ * Grigorieff 2015; third-party semantics, parity unpinned (oracle/thirdparty_semantics.py). */
+int mc_dose_accumulate(const void* S, int nframes, int frame0, int total_frames, void* A, int W,
+                       int H, float pixel_size, float pre_exposure, float dose_per_frame,
+                       float voltage, int first, int last, void* stream);
+
 /* Row-transform engine of K1: 0 = automatic (W == 4096, nkx <= 512, no per-job exponents,
  * 16-byte aligned src/mask and row_stride % 4 == 0 -> one wavefront per row, mc_wave_fft.h;
  * job_off[] must then be multiples of 4 floats, as whole-frame offsets f*h*w are),

@@ -25,6 +25,7 @@ Pinning status (see DESIGN.md section "Oracle"):
 from oracle.motion import (  # noqa: F401
     correct_motion,
     correct_motion_fast,
+    dose_weighted_sum,
     estimate_global_motion,
     estimate_motion_cross_correlation_patches,
     evaluate_deformation_field,

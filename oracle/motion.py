@@ -301,3 +301,13 @@ def estimate_motion_cross_correlation_patches(
         field = _smooth_time(field, smoothing_window_size)
     field = field - torch.mean(field)  # Q6: one scalar for both channels
     return field, centers
+
+
+def dose_weighted_sum(movie, pixel_spacing, dose_per_frame, pre_exposure=0.0, voltage=300.0):
+    """The reference pipeline's ``dose_weight(movie)`` (examples/ttMotion.py:331-351): rfft2
+    (ortho) -> dose_weight_movie -> irfft2 (ortho) -> sum over frames.  Third-party filter
+    semantics from thirdparty_semantics.dose_weight_movie: parity unpinned."""
+    shape = (movie.shape[-2], movie.shape[-1])
+    dft = torch.fft.rfft2(movie.float(), dim=(-2, -1), norm="ortho")
+    dw = tp.dose_weight_movie(dft, shape, pixel_spacing, pre_exposure, dose_per_frame, voltage)
+    return torch.fft.irfft2(dw, s=shape, dim=(-2, -1), norm="ortho").sum(dim=0)

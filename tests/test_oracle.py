@@ -234,3 +234,25 @@ def test_outlier_rejection_rules():
     same = torch.full((2, 2), 1.5)
     ry, rx = _reject_outliers(same, same, 3.0)  # zero spread: nothing rejected
     assert torch.equal(ry, same)
+
+
+def test_dose_weighted_sum_properties():
+    """Exposure-filtered frame sum of the reference's example pipeline
+    (examples/ttMotion.py:331-351); third-party filter semantics: parity unpinned, so only
+    the properties that hold for any exp(-0.5 N/N_c) filter with power restoration."""
+    g = torch.Generator().manual_seed(3)
+    m = torch.randn(6, 48, 64, generator=g) + 2.0
+    # zero dose: every weight is 1 -> plain sum / sqrt(t)
+    z = oracle.dose_weighted_sum(m, 1.0, 0.0)
+    assert torch.allclose(z, m.sum(0) / 6**0.5, atol=1e-4)
+    # the DC term keeps weight ~1 for any dose: mean(sum) = sum of means / sqrt(t)
+    d = oracle.dose_weighted_sum(m, 1.3, 2.0, pre_exposure=1.0)
+    assert float(d.mean()) == pytest.approx(float(m.sum(0).mean()) / 6**0.5, rel=1e-4)
+    # high frequencies are damped more than low ones, later frames more than early ones
+    f = tp.fftfreq_grid((48, 64), rfft=True, norm=True)
+    w = tp.dose_weight_movie(torch.ones(6, 48, 33, dtype=torch.complex64), (48, 64), 1.3, 1.0, 2.0).real
+    assert float(w[-1][f > 0.4].mean()) < float(w[0][f > 0.4].mean())
+    assert torch.allclose((w**2).sum(0), torch.ones(48, 33), atol=1e-5)  # power restored
+    # linear in the movie
+    assert torch.allclose(oracle.dose_weighted_sum(3 * m, 1.3, 2.0), 3 * oracle.dose_weighted_sum(m, 1.3, 2.0),
+                          atol=1e-4)

@@ -6,6 +6,7 @@ behind a C ABI (include/mcorr.h, libmcorr.so).  There is no CPU fallback."""
 from .api import (  # noqa: F401
     correct_motion,
     correct_motion_fast,
+    dose_weighted_sum,
     estimate_global_motion,
     estimate_motion,
     estimate_motion_cross_correlation_patches,
@@ -28,6 +29,7 @@ __all__ = [
     "estimate_motion_cross_correlation_patches",
     "estimate_motion",
     "motion_correct_sum",
+    "dose_weighted_sum",
     "evaluate_deformation_field_at_t",
     "resample_deformation_field",
     "image_shifts_to_deformation_field",

@@ -195,17 +195,37 @@ def correct_motion(image, deformation_grid, pixel_spacing, grad=False, grid_type
 
 
 def motion_correct_sum(image, deformation_grid, pixel_spacing, grid_type="catmull_rom", device=None,
-                       return_frames=False):
+                       return_frames=False, dose_per_frame=None, pre_exposure=0.0, voltage=300.0):
     """Fused correct_motion + the caller-side ``torch.sum(movie, dim=0)`` of the
     reference's pipeline (examples/ttMotion.py:398): returns the (h,w) aligned sum
-    (and the frames when asked) without a second pass over the stack."""
+    (and the frames when asked) without a second pass over the stack.  With
+    ``dose_per_frame`` (e/A^2) the sum is exposure-filtered as in the reference's
+    ``dose_weight`` step (examples/ttMotion.py:331-351; see ``dose_weighted_sum``)."""
     out_dev = _out_device(image, device)
     dev = require_gpu(out_dev)
     img = _stage(image, dev)
     lat = engine.frame_lattices(_stage(deformation_grid, dev), img.shape[0], grid_type)
-    frames, total = engine.warp(img, lat, float(pixel_spacing), want_frames=return_frames, want_sum=True,
-                                rigid=RIGID_FAST_PATH and _is_rigid(deformation_grid))
+    rigid = RIGID_FAST_PATH and _is_rigid(deformation_grid)
+    if dose_per_frame is None:
+        frames, total = engine.warp(img, lat, float(pixel_spacing), want_frames=return_frames, want_sum=True,
+                                    rigid=rigid)
+    else:
+        frames, _ = engine.warp(img, lat, float(pixel_spacing), want_frames=True, want_sum=False, rigid=rigid)
+        total = engine.dose_weighted_sum(frames, float(pixel_spacing), float(dose_per_frame),
+                                         float(pre_exposure), float(voltage))
     return (total.to(out_dev), frames.to(out_dev)) if return_frames else total.to(out_dev)
+
+
+def dose_weighted_sum(movie, pixel_spacing, dose_per_frame, pre_exposure=0.0, voltage=300.0, device=None):
+    """``sum_f irfft2(q_f * rfft2(frame_f))`` with the Grant & Grigorieff exposure filter
+    ``q_f = exp(-0.5 N_f / N_c(|k|))`` normalised by ``sqrt(sum_f q_f^2)``: the reference
+    pipeline's ``dose_weight(movie)`` (examples/ttMotion.py:331-351: rfft2(norm='ortho') ->
+    torch_fourier_filter dose_weight_movie(crit_exposure_bfactor=-1) -> irfft2 -> sum).  The
+    third-party filter is not part of the reference tree and untested there: parity unpinned."""
+    out_dev = _out_device(movie, device)
+    dev = require_gpu(out_dev)
+    return engine.dose_weighted_sum(_stage(movie, dev), float(pixel_spacing), float(dose_per_frame),
+                                    float(pre_exposure), float(voltage)).to(out_dev)
 
 
 def _correct_motion_fast_impl(img_dev, deformation_grid, dev, mutate):

@@ -432,6 +432,53 @@ def fourier_shift(img, shifts):
     return out
 
 
+def dose_weighted_sum(img, pixel_spacing, dose_per_frame, pre_exposure=0.0, voltage=300.0):
+    """sum_f irfft2(q_f * rfft2(frame_f)): the exposure-filtered frame sum of the reference's
+    example pipeline (examples/ttMotion.py:331-351, 398) with ONE inverse transform per movie:
+    full spectra of a chunk of frames (K1+K2, no mask / filter) -> mc_dose_accumulate -> inverse
+    column and row passes.  Semantics of the absent third-party filter: parity unpinned."""
+    lib = _lib.load()
+    t, h, w = img.shape
+    dev = img.device
+    g = planmod.full_geometry(h, w)
+    tw_row, tw_col = planmod.get_twiddles(w, dev), planmod.get_twiddles(h, dev)
+    per_frame = g.nkx * g.H * 8
+    chunk = max(1, min(t, WORKSPACE_BYTES // (2 * per_frame)))
+    T1 = torch.empty((chunk, g.nkx, g.ny, 2), dtype=torch.float32, device=dev)
+    S = torch.empty((chunk, g.nkx, g.nky, 2), dtype=torch.float32, device=dev)
+    A = torch.empty((1, g.nkx, g.nky, 2), dtype=torch.float32, device=dev)
+    st = stream_ptr(dev)
+    for a in range(0, t, chunk):
+        n = min(chunk, t - a)
+        off = torch.arange(a, a + n, device=dev, dtype=torch.int64) * (h * w)
+        check(_k1(lib, g, dev, img, off, w, None, None, None, T1, tw_row, n, st), "xc rows forward")
+        check(_k2(lib, g, dev, T1, None, S, tw_col, n, st), "xc cols forward")
+        check(lib.mc_dose_accumulate(ptr(S), n, a, t, ptr(A), w, h, float(pixel_spacing), float(pre_exposure),
+                                     float(dose_per_frame), float(voltage), 1 if a == 0 else 0,
+                                     1 if a + n >= t else 0, st), "mc_dose_accumulate")
+    # inverse of the single accumulated spectrum: Fourier-shift path with a zero shift
+    out = torch.empty((1, h, w), dtype=torch.float32, device=dev)
+    idx = torch.zeros(1, device=dev, dtype=torch.int32)
+    zero = torch.zeros((1, 2), device=dev, dtype=torch.float32)
+    off0 = torch.zeros(1, device=dev, dtype=torch.int64)
+    T2 = T1[:1] if g.ny == g.H else torch.empty((1, g.nkx, g.H, 2), dtype=torch.float32, device=dev)
+    if _pow2(g.H):
+        check(lib.mc_fourier_shift_cols_inverse(ptr(A), ptr(idx), ptr(zero), ptr(T2), ptr(tw_col),
+                                                1.0 / (h * w), 1, g, st), "mc_fourier_shift_cols_inverse")
+    else:
+        line, _ = planmod.line_plan(g.H, +1, dev)
+        check(lib.mc_xcg_cols_inverse(ptr(A), ptr(idx), None, None, ptr(zero), ptr(T2), line,
+                                      1.0 / (h * w), 1, g, st), "mc_xcg_cols_inverse")
+    if _pow2(g.W):
+        check(lib.mc_xc_rows_inverse_store(ptr(T2), ptr(out), ptr(off0), w, ptr(tw_row), 1, g, st),
+              "mc_xc_rows_inverse_store")
+    else:
+        line, _ = planmod.line_plan(g.W // 2, +1, dev)
+        check(lib.mc_xcg_rows_inverse(ptr(T2), None, None, None, None, ptr(out), ptr(off0), w,
+                                      ptr(tw_row), line, 1, g, st), "mc_xcg_rows_inverse")
+    return out[0]
+
+
 def sum_frames(frames):
     lib = _lib.load()
     t, h, w = frames.shape
