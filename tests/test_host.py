@@ -285,3 +285,31 @@ def test_movie_pipeline_needs_a_gpu_and_is_exported():
     if not torch.cuda.is_available():
         with pytest.raises(m.McorrError):
             m.motion_correct_movies([torch.zeros(2, 64, 64)], 1.0)
+
+
+def test_deformation_field_csv_round_trip_and_wire_format(tmp_path):
+    """N4: CSV interchange identical to the reference's data_io.py (header, row order,
+    float64 images of the float32 values; sorted-unique index axes on read)."""
+    import torch_motion_correction_amd as m
+
+    g = torch.Generator().manual_seed(4)
+    field = torch.randn(2, 3, 2, 4, generator=g)
+    p = tmp_path / "sub" / "field.csv"
+    m.write_deformation_field_to_csv(field, p)
+    lines = p.read_text().strip().split("\n")
+    assert lines[0] == "t,h,w,y_shift,x_shift" and len(lines) == 1 + 3 * 2 * 4
+    # the reference's own writer, element by element (data_io.py:39-62)
+    t_, h_, w_, y_, x_ = lines[1 + (1 * 2 + 1) * 4 + 2].split(",")
+    assert (int(t_), int(h_), int(w_)) == (1, 1, 2)
+    assert float(y_) == field[0, 1, 1, 2].item() and float(x_) == field[1, 1, 1, 2].item()
+    assert y_ == repr(field[0, 1, 1, 2].item())
+    back = m.read_deformation_field_from_csv(p)
+    assert back.dtype == torch.float32 and back.device.type == "cpu" and torch.equal(back, field)
+    # non-contiguous index values: axes are the sorted sets of values (data_io.py:103-120)
+    q = tmp_path / "gaps.csv"
+    q.write_text("t,h,w,y_shift,x_shift\n5,0,7,1.5,-2.0\n2,0,3,0.25,4.0\n")
+    gaps = m.read_deformation_field_from_csv(q)
+    assert gaps.shape == (2, 2, 1, 2)
+    assert gaps[0, 0, 0, 0] == 0.25 and gaps[1, 1, 0, 1] == -2.0 and gaps[0, 1, 0, 0] == 0.0
+    with pytest.raises(ValueError):
+        m.write_deformation_field_to_csv(torch.zeros(3, 2, 2), p)

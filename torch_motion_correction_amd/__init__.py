@@ -18,6 +18,7 @@ from .api import (  # noqa: F401
     resample_deformation_field,
 )
 from ._lib import McorrError  # noqa: F401
+from .data_io import read_deformation_field_from_csv, write_deformation_field_to_csv  # noqa: F401
 from .pipeline import MoviePipeline, MovieResult, motion_correct_movies  # noqa: F401
 
 __all__ = [
@@ -34,6 +35,8 @@ __all__ = [
     "resample_deformation_field",
     "image_shifts_to_deformation_field",
     "McorrError",
+    "write_deformation_field_to_csv",
+    "read_deformation_field_from_csv",
     "motion_correct_movies",
     "MoviePipeline",
     "MovieResult",
