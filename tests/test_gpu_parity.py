@@ -528,12 +528,13 @@ def test_odd_width_is_rejected_loudly(mc, dev):
 # ------------------------------------------------------------------ wave-per-row K1
 
 
-@pytest.mark.parametrize("h", [4096, 512])
-def test_wave_row_engine_matches_workgroup_engine(dev, h):
+@pytest.mark.parametrize("h,fr", [(4096, (300, 10)), (512, (300, 10)), (1024, (300, 20))])
+def test_wave_row_engine_matches_workgroup_engine(dev, h, fr):
     """The wavefront-per-row K1 (mc_wave_fft.h; W = 4096, nkx <= 512) against the
     workgroup-per-row K1 on the same frames: T1, the fused box statistics, and the
     final filtered spectra.  h = 512 puts the mask support inside chunks 7..8 of the row
-    (clamped sample loads + exact mask zeros), h = 4096 is the benchmark geometry."""
+    (clamped sample loads + exact mask zeros), h = 4096 is the benchmark geometry, the
+    (300, 20) band keeps nkx <= 256 (one kept radix-8 output pair per butterfly)."""
     from torch_motion_correction_amd import _lib, engine, plan
     from torch_motion_correction_amd._lib import check, ptr, stream_ptr
 
@@ -541,13 +542,15 @@ def test_wave_row_engine_matches_workgroup_engine(dev, h):
     w, t = 4096, 2
     g = torch.Generator().manual_seed(h)
     img = (torch.randn(t, h, w, generator=g) * 1.7 + 11.0).to(dev)
-    pl = plan.get_xc_plan(h, w, 1.0, 500.0, (300, 10), dev)
+    pl = plan.get_xc_plan(h, w, 1.0, 500.0, fr, dev)
     gm = pl.geom
-    assert gm.nkx <= 512 and gm.ny % 8 == 0
+    assert gm.nkx <= 512 and gm.ny % 8 == 0 and (gm.nkx <= 256) == (fr[1] == 20)
     off = torch.arange(t, device=dev, dtype=torch.int64) * (h * w)
     hl, hu, wl, wu = int(0.25 * h), int(0.75 * h), int(0.25 * w), int(0.75 * w)
-    if h == 512:  # the statistics box must lie inside the region K1 reads
-        wl, wu = 1900, 2200
+    if h == 512:  # the statistics box must lie inside the region K1 reads; unaligned to the
+        wl, wu = 1900, 2200  # 256-px chunks here: the fused statistics stay on the workgroup kernel
+    elif h == 1024:
+        wl, wu = 1792, 2304  # chunk-aligned: fused statistics on the wave kernel
     assert gm.x0 <= wl and wu <= gm.x1 and gm.y0 <= hl and hu <= gm.y0 + gm.ny
     m0 = torch.tensor([11.0, 1.0, 1.0], device=dev)
     res = {}
