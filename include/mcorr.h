@@ -83,6 +83,17 @@ int mc_dose_accumulate(const void* S, int nframes, int frame0, int total_frames,
                        int H, float pixel_size, float pre_exposure, float dose_per_frame,
                        float voltage, int first, int last, void* stream);
 
+/* K1 for rows of 1024 samples (1024 x 1024 patches; needs W == 1024, nkx <= 128, ny % 8 == 0,
+ * a mask, every exponent >= 1; MC_ERR_UNSUPPORTED otherwise): one wavefront per row, and with
+ * expo_b != NULL the same samples are transformed twice, with mask^expo_a[j] into T1a and
+ * mask^expo_b[j] into T1b -- the U and V spectra of the mean-except-current reference
+ * (estimate_motion_xc.py:315-346) from one read of the patch rows.  Layouts as
+ * mc_xc_rows_forward. */
+int mc_xc_rows_forward_dual(const float* src, const int64_t* job_off, int64_t row_stride,
+                            const int* expo_a, const int* expo_b, const float* mask,
+                            const float* mean_rstd, void* T1a, void* T1b, const void* tw_row,
+                            int njobs, const mc_xc_geom* geom, void* stream);
+
 /* Row-transform engine of K1: 0 = automatic (W == 4096, nkx <= 512, no per-job exponents,
  * 16-byte aligned src/mask and row_stride % 4 == 0 -> one wavefront per row, mc_wave_fft.h;
  * job_off[] must then be multiples of 4 floats, as whole-frame offsets f*h*w are),

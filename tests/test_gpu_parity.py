@@ -675,3 +675,41 @@ def test_motion_correct_sum_with_dose_weighting(mc, dev):
     # zero dose = plain sum / sqrt(t)
     z = mc.motion_correct_sum(st.to(dev), field, 1.0, dose_per_frame=0.0).cpu()
     assert float((z - plain.sum(0).cpu() / 6**0.5).abs().max()) <= 1e-4 * float(z.abs().max())
+
+
+# ------------------------------------------------------------------ wave-per-row K1, patch rows
+
+
+def test_wave512_patch_rows_match_workgroup_engine(dev):
+    """mc_xc_rows_forward_dual (one wavefront per 1024-sample row, U and V from one read)
+    against the workgroup-per-row K1 run twice, on patch jobs at odd and even offsets."""
+    from torch_motion_correction_amd import _lib, plan
+    from torch_motion_correction_amd._lib import check, ptr, stream_ptr
+
+    lib = _lib.load()
+    p, h, w = 1024, 1500, 2200
+    g = torch.Generator().manual_seed(8)
+    img = (torch.randn(2, h, w, generator=g) * 1.3 + 4.0).to(dev)
+    pl = plan.get_xc_plan(p, p, 1.0, 500.0, (300, 10), dev)
+    gm = pl.geom
+    assert gm.W == 1024 and gm.nkx <= 128 and gm.ny % 8 == 0
+    origins = [0, 7 * w + 13, 300 * w + 1101, h * w + 476 * w + 1176]  # odd and even x offsets
+    off = torch.tensor(origins, dtype=torch.int64, device=dev)
+    n = len(origins)
+    ea = torch.tensor([1, 2, 1, 3], dtype=torch.int32, device=dev)
+    eb = torch.tensor([2, 4, 2, 1], dtype=torch.int32, device=dev)
+    stats = torch.tensor([4.0, 0.7], device=dev)
+    st = stream_ptr(dev)
+    Ua, Ub, Ra, Rb, Sa = (torch.zeros((n, gm.nkx, gm.ny, 2), device=dev) for _ in range(5))
+    check(lib.mc_xc_rows_forward_dual(ptr(img), ptr(off), w, ptr(ea), ptr(eb), ptr(pl.mask), ptr(stats), ptr(Ua),
+                                      ptr(Ub), ptr(pl.tw_row), n, gm, st), "dual")
+    check(lib.mc_xc_rows_forward_dual(ptr(img), ptr(off), w, ptr(ea), None, ptr(pl.mask), ptr(stats), ptr(Sa), None,
+                                      ptr(pl.tw_row), n, gm, st), "single")
+    check(lib.mc_xc_rows_forward(ptr(img), ptr(off), w, ptr(ea), ptr(pl.mask), ptr(stats), ptr(Ra), ptr(pl.tw_row),
+                                 n, gm, st), "wg a")
+    check(lib.mc_xc_rows_forward(ptr(img), ptr(off), w, ptr(eb), ptr(pl.mask), ptr(stats), ptr(Rb), ptr(pl.tw_row),
+                                 n, gm, st), "wg b")
+    for got, ref in ((Ua, Ra), (Ub, Rb), (Sa, Ra)):
+        got, ref = got.cpu(), ref.cpu()
+        assert torch.isfinite(got).all()
+        assert float((got - ref).abs().max()) <= 3e-6 * float(ref.abs().max())

@@ -232,3 +232,41 @@ MC_HD void wf_unpack_lane(const wf2 (&z)[4][8], const wf2 (&wk)[4], bool self, w
     X[3][k3] = wf_unpack(z[3][k3], z[2][7 - k3], w[3]);
   }
 }
+
+// =====================================================================================
+// 512-point variant (= one real row of 1024 samples: the rows of 1024 x 1024 patches).
+// N = 8 x 8 x 8, eight complex values per lane, ONE radix-8 butterfly per lane and pass:
+//   n = 64 n1 + 8 n2 + n3,   k = k1 + 8 k2 + 64 k3
+//   pass A  radix 8 over n1, twiddle W_512^{q k1}   lane t owns q = 8 n2 + n3 = t
+//   pass B  radix 8 over n2, twiddle W_64^{n3 k2}   lane t owns (k1, n3) = (t & 7, t >> 3)
+//   pass C  radix 8 over n3                          lane t owns c = k1 + 8 k2 = t
+// Two whole-line exchanges through a 512-entry (4 KiB) wave-private slab.  Bin k = t + 64 k3
+// pairs with bin 512 - k, which lives in lane (64 - t) & 63 at 7 - k3 (lane 0: itself at
+// (8 - k3) & 7): the real-FFT unpack fetches it with a lane permute instead of a third
+// exchange.  Only k3 in {0, 1} (k < 128) and their partners {7, 6} are produced.
+// =====================================================================================
+#define WF5_N 512
+#define WF5_SLAB 512
+
+MC_HD void wf_dft8(wf2 (&a)[8]) {  // full forward 8-point DFT, natural order in and out
+  const float H = 0.70710678118654752440f;
+  wf2 e0 = a[0], e1 = a[2], e2 = a[4], e3 = a[6];
+  wf2 o0 = a[1], o1 = a[3], o2 = a[5], o3 = a[7];
+  wf_bfly4(e0, e1, e2, e3);
+  wf_bfly4(o0, o1, o2, o3);
+  a[0] = e0 + o0;
+  a[4] = e0 - o0;
+  a[1] = wf_fma_c(e1, o1, H, -H);
+  a[5] = wf_fma_c(e1, o1, -H, H);
+  a[2] = wf_add_mi(e2, o2);
+  a[6] = wf_sub_mi(e2, o2);
+  a[3] = wf_fma_c(e3, o3, -H, -H);
+  a[7] = wf_fma_c(e3, o3, H, H);
+}
+
+// Slab addresses (complex index < 512), conflict-free for ds_write_b64 (16-lane groups) and
+// ds_read_b64 (32-lane groups):
+//   exchange 1: entry (k1, n2, n3) at ((n2 * 8 + (k1 ^ n2)) * 8) + (n3 ^ (4 * (k1 >> 2)))
+//   exchange 2: entry (k2, n3, k1) at ((n3 * 8 + (k2 ^ n3)) * 8) + k1
+MC_HD int wf5_x1(int k1, int n2, int n3) { return ((n2 * 8 + (k1 ^ n2)) * 8) + (n3 ^ (4 * (k1 >> 2))); }
+MC_HD int wf5_x2(int k2, int n3, int k1) { return ((n3 * 8 + (k2 ^ n3)) * 8) + k1; }

@@ -485,6 +485,160 @@ __global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
   }
 }
 
+// ------------------------------------------------------------------ K1, wave per 1024-sample row
+// Patch rows (W = 1024, N = 512 complex points, nkx <= 128): the 8 x 8 x 8 variant of the
+// wave engine (mc_wave_fft.h, second half) -- eight complex values per lane, one radix-8
+// butterfly per lane and pass, a 4 KiB slab per wave.  DUAL: the same samples are transformed
+// twice, with mask^ea and mask^eb (the U and V spectra of the mean-except-current reference,
+// estimate_motion_xc.py:315-346), so the patch rows are read once instead of twice.
+// Exponents must be >= 1 (the mask's exact zeros outside its support do the windowing).
+#define WF5_TWA (7 * 64)
+#define WF5_TWB (8 * 7)
+#define WF5_TWK 128
+
+__device__ __forceinline__ wf2 wf5_ld2(const float* p) {  // 4-byte aligned 8-byte load
+  wf2 v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+
+__device__ __forceinline__ void wf5_fft(wf2 (&A)[8], int t, wf2* slab, const wf2* twA, const wf2* twB,
+                                        const wf2* twK, wf2 (&X)[2]) {
+  const int lo = t & 7, hi = t >> 3;
+  wf_dft8(A);
+#pragma unroll
+  for (int k1 = 1; k1 < 8; ++k1) A[k1] = wf_cmul(A[k1], twA[(k1 - 1) * 64 + t]);
+#pragma unroll
+  for (int k1 = 0; k1 < 8; ++k1) slab[wf5_x1(k1, hi, lo)] = A[k1];  // source: n2 = t >> 3, n3 = t & 7
+  wf_sync();
+  wf2 B[8];
+#pragma unroll
+  for (int n2 = 0; n2 < 8; ++n2) B[n2] = slab[wf5_x1(lo, n2, hi)];  // dest: k1 = t & 7, n3 = t >> 3
+  wf_sync();
+  wf_dft8(B);
+#pragma unroll
+  for (int k2 = 1; k2 < 8; ++k2) B[k2] = wf_cmul(B[k2], twB[hi * 7 + k2 - 1]);
+#pragma unroll
+  for (int k2 = 0; k2 < 8; ++k2) slab[wf5_x2(k2, hi, lo)] = B[k2];
+  wf_sync();
+  wf2 e[4], o[4], z[8];
+#pragma unroll
+  for (int n3 = 0; n3 < 8; ++n3) {  // dest: c = t = k1 + 8 k2
+    const wf2 v = slab[wf5_x2(hi, n3, lo)];
+    if (n3 & 1) o[n3 >> 1] = v; else e[n3 >> 1] = v;
+  }
+  wf_sync();
+  wf_dft8_pruned<2>(e, o, z);
+  // bin 512 - k lives in lane (64 - t) & 63 at 7 - k3 (lane 0: itself at (8 - k3) & 7)
+  const int p = (64 - t) & 63;
+  const wf2 zp7 = wf2{__shfl(z[7].x, p), __shfl(z[7].y, p)};
+  const wf2 zp6 = wf2{__shfl(z[6].x, p), __shfl(z[6].y, p)};
+  const wf2 m0 = t == 0 ? z[0] : zp7, m1 = t == 0 ? zp7 : zp6;
+  X[0] = wf_unpack(z[0], m0, twK[t]);
+  X[1] = wf_unpack(z[1], m1, twK[t + 64]);
+}
+
+template <bool DUAL>
+__global__ __launch_bounds__(256) void xc_rows_fwd_wave512(
+    const float* __restrict__ src, const int64_t* __restrict__ job_off, int64_t row_stride,
+    const int* __restrict__ expo_a, const int* __restrict__ expo_b, const float* __restrict__ mask,
+    const float* __restrict__ mean_rstd, cfloat* __restrict__ T1a, cfloat* __restrict__ T1b,
+    const cfloat* __restrict__ tw_row, XcGeom g) {
+  __shared__ __attribute__((aligned(16))) wf2 slabs[4][WF5_SLAB];
+  __shared__ __attribute__((aligned(16))) wf2 tab[WF5_TWA + WF5_TWB + WF5_TWK];
+  const wf2* twA = tab;
+  const wf2* twB = tab + WF5_TWA;
+  const wf2* twK = tab + WF5_TWA + WF5_TWB;
+  const int t = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  wf2* slab = slabs[wv];
+  const int job = blockIdx.x, grp = blockIdx.y;
+  {  // tables from tw_row[k] = exp(-2 pi i k / 1024): W_512^m = tw_row[2 m], W_64^m = tw_row[16 m]
+    constexpr int NTAB = WF5_TWA + WF5_TWB + WF5_TWK, PER = (NTAB + 255) / 256;
+    cfloat tv[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      int i = threadIdx.x + 256 * j;
+      i = i < NTAB ? i : NTAB - 1;
+      int src_k;
+      if (i < WF5_TWA) src_k = 2 * (i & 63) * ((i >> 6) + 1);
+      else if (i < WF5_TWA + WF5_TWB) src_k = 16 * ((i - WF5_TWA) / 7) * ((i - WF5_TWA) % 7 + 1);
+      else src_k = i - WF5_TWA - WF5_TWB;
+      tv[j] = tw_row[src_k];
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = threadIdx.x + 256 * j;
+      if (i < NTAB) tab[i] = wf_from(tv[j]);
+    }
+  }
+  const float mean = mean_rstd ? mean_rstd[0] : 0.f;
+  const float rstd = mean_rstd ? mean_rstd[1] : 1.f;
+  const int ea = expo_a[job], eb = DUAL ? expo_b[job] : 1;
+  const float* base = src + job_off[job];
+  cfloat* outa = T1a + (int64_t)job * g.nkx * g.ny;
+  cfloat* outb = DUAL ? T1b + (int64_t)job * g.nkx * g.ny : nullptr;
+  const int r16 = grp * 16;
+  const int nrows = g.ny - r16 >= 16 ? 4 : (g.ny - r16 >= 8 ? 2 : 0);  // ny % 8 == 0
+  const int xlo = g.x0, xhi = g.x1 - 2;  // both even: a pair of samples is in or out as a whole
+  __syncthreads();
+  wf2 Xae[2], Xbe[2];  // bins of the even row of the current pair
+#pragma unroll 1
+  for (int rr = 0; rr < nrows; ++rr) {
+    const int r = r16 + (rr >> 1) * 8 + 2 * wv + (rr & 1);
+    const int y = g.y0 + r;
+    int tl = t;
+    asm volatile("" : "+v"(tl));  // per-row addresses are re-derived, not carried (registers)
+    const float* row = base + (int64_t)y * row_stride;
+    const float* mrow = mask + (int64_t)y * g.W;
+    wf2 A[8], Bv[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) {
+      const int x = 128 * n1 + 2 * tl;
+      const wf2 px = wf5_ld2(row + min(max(x, xlo), xhi));  // outside the support: mask == 0
+      const wf2 m = *reinterpret_cast<const wf2*>(mrow + x);
+      const wf2 a = (px - mean) * rstd;
+      wf2 ma = m;
+      for (int e = 1; e < ea; ++e) ma *= m;
+      A[n1] = a * ma;
+      if (DUAL) {
+        wf2 mb = m;
+        for (int e = 1; e < eb; ++e) mb *= m;
+        Bv[n1] = a * mb;
+      }
+    }
+    wf2 Xa[2], Xb[2];
+    wf5_fft(A, tl, slab, twA, twB, twK, Xa);
+    if (DUAL) wf5_fft(Bv, tl, slab, twA, twB, twK, Xb);
+    if (rr & 1) {
+      float4* park = reinterpret_cast<float4*>(slab);  // [spectrum][128 kx] = {even row, odd row}
+      park[tl] = make_float4(Xae[0].x, Xae[0].y, Xa[0].x, Xa[0].y);
+      park[tl + 64] = make_float4(Xae[1].x, Xae[1].y, Xa[1].x, Xa[1].y);
+      if (DUAL) {
+        park[128 + tl] = make_float4(Xbe[0].x, Xbe[0].y, Xb[0].x, Xb[0].y);
+        park[128 + tl + 64] = make_float4(Xbe[1].x, Xbe[1].y, Xb[1].x, Xb[1].y);
+      }
+      __syncthreads();
+      {
+        const int r8 = r16 + (rr >> 1) * 8;
+        const float4* parked = reinterpret_cast<const float4*>(&slabs[0][0]);
+        const int per = 4 * g.nkx;  // 4 lanes = the 64 bytes (8 rows) of one kx
+        for (int j = threadIdx.x; j < (DUAL ? 2 : 1) * per; j += 256) {
+          const int sp = j >= per, jj = j - sp * per;
+          const int kx = jj >> 2, w = jj & 3;
+          cfloat* out = sp ? outb : outa;
+          *reinterpret_cast<float4*>(out + (int64_t)kx * g.ny + r8 + 2 * w) =
+              parked[w * (WF5_SLAB / 2) + sp * 128 + kx];
+        }
+      }
+      __syncthreads();
+    } else {
+      Xae[0] = Xa[0]; Xae[1] = Xa[1];
+      if (DUAL) { Xbe[0] = Xb[0]; Xbe[1] = Xb[1]; }
+    }
+  }
+}
+
 // (sum, sumsq) of (x - m0) over `count` samples, spread over XC_STAT_SLOTS accumulators
 // -> fix = {mean - m0, 1/std}, out3 = {mean, 1/std, std}  (unbiased std, as
 // torch.std_mean, utils.py:81)
@@ -1067,6 +1221,29 @@ static int rows_forward_impl(const float* src, const int64_t* job_off, int64_t r
     hipLaunchKernelGGL(k, grid, dim3(MC_WG), lds, (hipStream_t)stream, src, job_off, row_stride,
                        job_expo, mask, mean_rstd, (cfloat*)T1, (const cfloat*)tw_row, g, b, stats_acc);
   });
+  return mc_check_launch();
+}
+
+int mc_xc_rows_forward_dual(const float* src, const int64_t* job_off, int64_t row_stride,
+                            const int* expo_a, const int* expo_b, const float* mask,
+                            const float* mean_rstd, void* T1a, void* T1b, const void* tw_row,
+                            int njobs, const mc_xc_geom* q, void* stream) {
+  XcGeom g;
+  int rc = geom_from(q, &g, true, false);
+  if (rc) return rc;
+  if (!src || !job_off || !expo_a || !mask || !T1a || !tw_row || njobs < 1 || (expo_b && !T1b))
+    return MC_ERR_ARG;
+  if (g.W != 2 * WF5_N || g.nkx > 128 || (g.ny % 8) || (reinterpret_cast<uintptr_t>(mask) & 7))
+    return MC_ERR_UNSUPPORTED;
+  dim3 grid(njobs, (g.ny + 15) / 16);
+  if (expo_b)
+    hipLaunchKernelGGL(xc_rows_fwd_wave512<true>, grid, dim3(256), 0, (hipStream_t)stream, src, job_off,
+                       row_stride, expo_a, expo_b, mask, mean_rstd, (cfloat*)T1a, (cfloat*)T1b,
+                       (const cfloat*)tw_row, g);
+  else
+    hipLaunchKernelGGL(xc_rows_fwd_wave512<false>, grid, dim3(256), 0, (hipStream_t)stream, src, job_off,
+                       row_stride, expo_a, (const int*)nullptr, mask, mean_rstd, (cfloat*)T1a,
+                       (cfloat*)nullptr, (const cfloat*)tw_row, g);
   return mc_check_launch();
 }
 

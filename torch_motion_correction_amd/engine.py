@@ -84,25 +84,50 @@ def _k2(lib, g, dev, T1, filt, S, tw_col, n, st):
     return lib.mc_xcg_cols_forward(ptr(T1), ptr(filt), ptr(S), line, n, g, st)
 
 
-def _forward_spectra(src, job_off, row_stride, job_expo, pl, stats, use_mask=True, use_filter=True):
-    """K1+K2 for a list of jobs -> S (njobs, nkx, nky, 2)."""
+def _wave512_ok(g, job_expo, use_mask, min_expo):
+    """Patch rows of 1024 samples can take the wave-per-row K1 (mc_xc_rows_forward_dual):
+    needs the mask and per-job exponents that are all >= 1 (`min_expo`, known on the host)."""
+    return (g.W == 1024 and g.nkx <= 128 and g.ny % 8 == 0 and use_mask and job_expo is not None
+            and min_expo is not None and min_expo >= 1)
+
+
+def _forward_spectra(src, job_off, row_stride, job_expo, pl, stats, use_mask=True, use_filter=True,
+                     job_expo_b=None, min_expo=None):
+    """K1+K2 for a list of jobs -> S (njobs, nkx, nky, 2).  With `job_expo_b` the rows are read
+    once and transformed twice (mask^job_expo and mask^job_expo_b): returns (S_a, S_b)."""
     lib = _lib.load()
     g, dev = pl.geom, src.device
     njobs = int(job_off.numel())
+    dual = job_expo_b is not None
+    wave = _wave512_ok(g, job_expo, use_mask, min_expo)
+    if dual and not wave:  # no fused kernel for this shape: two ordinary passes
+        return (_forward_spectra(src, job_off, row_stride, job_expo, pl, stats, use_mask, use_filter),
+                _forward_spectra(src, job_off, row_stride, job_expo_b, pl, stats, use_mask, use_filter))
     S = torch.empty((njobs, g.nkx, g.nky, 2), dtype=torch.float32, device=dev)
-    per_job = g.nkx * g.ny * 8
+    Sb = torch.empty_like(S) if dual else None
+    per_job = g.nkx * g.ny * 8 * (2 if dual else 1)
     chunk = max(1, min(njobs, WORKSPACE_BYTES // per_job))
     T1 = torch.empty((chunk, g.nkx, g.ny, 2), dtype=torch.float32, device=dev)
+    T1b = torch.empty_like(T1) if dual else None
     st = stream_ptr(dev)
     for a in range(0, njobs, chunk):
         n = min(chunk, njobs - a)
         off = job_off[a : a + n]
         expo = None if job_expo is None else job_expo[a : a + n]
-        check(_k1(lib, g, dev, src, off, row_stride, expo, pl.mask if use_mask else None, stats, T1,
-                  pl.tw_row, n, st), "xc rows forward")
+        if wave:
+            expo_b = job_expo_b[a : a + n] if dual else None
+            check(lib.mc_xc_rows_forward_dual(ptr(src), ptr(off), row_stride, ptr(expo), ptr(expo_b),
+                                              ptr(pl.mask), ptr(stats), ptr(T1), ptr(T1b), ptr(pl.tw_row),
+                                              n, g, st), "mc_xc_rows_forward_dual")
+        else:
+            check(_k1(lib, g, dev, src, off, row_stride, expo, pl.mask if use_mask else None, stats, T1,
+                      pl.tw_row, n, st), "xc rows forward")
         check(_k2(lib, g, dev, T1, pl.filt if use_filter else None, S[a : a + n], pl.tw_col, n, st),
               "xc cols forward")
-    return S
+        if dual:
+            check(_k2(lib, g, dev, T1b, pl.filt if use_filter else None, Sb[a : a + n], pl.tw_col, n, st),
+                  "xc cols forward")
+    return (S, Sb) if dual else S
 
 
 def _peaks(S_cur, cur_idx, S_ref, ref_idx, pl, want_nbhd):
@@ -272,8 +297,7 @@ def patch_field(img, stats, pixel_spacing, reference_frame, reference_strategy, 
             if ref_expo.max() > 1 or cur_expo.max() > 0:
                 raise NotImplementedError("unexpected mask schedule")
             off, ex1 = jobs(range(t), [1] * t)
-            U = _forward_spectra(img, off, w, ex1, pl, stats)
-            V = _forward_spectra(img, off, w, ex1 * 2, pl, stats)
+            U, V = _forward_spectra(img, off, w, ex1, pl, stats, job_expo_b=ex1 * 2, min_expo=1)
             sp, si, sr = lattice.leave_one_out_schedule(ref_expo)
             sp, si, sr = _i32(sp, dev), _i32(si, dev), torch.as_tensor(sr, device=dev)
             REF = torch.empty_like(U)
@@ -283,11 +307,12 @@ def patch_field(img, stats, pixel_spacing, reference_frame, reference_strategy, 
             del V
             S_cur, S_ref = U, REF
         else:
-            off, ex = jobs(processed, [int(cur_expo[f]) + 1 for f in processed])
-            S_cur = _forward_spectra(img, off, w, ex, pl, stats)
-            off, ex = jobs([reference_frame] * nproc,
-                           [int(ref_expo[f, reference_frame]) + 1 for f in processed])
-            S_ref = _forward_spectra(img, off, w, ex, pl, stats)
+            exl = [int(cur_expo[f]) + 1 for f in processed]
+            off, ex = jobs(processed, exl)
+            S_cur = _forward_spectra(img, off, w, ex, pl, stats, min_expo=min(exl))
+            exl = [int(ref_expo[f, reference_frame]) + 1 for f in processed]
+            off, ex = jobs([reference_frame] * nproc, exl)
+            S_ref = _forward_spectra(img, off, w, ex, pl, stats, min_expo=min(exl))
         pair_idx = torch.arange(nproc * npatch, device=dev, dtype=torch.int32)
         peaks, _, nb = _peaks(S_cur, pair_idx, S_ref, pair_idx, pl, want_nbhd=sub_pixel_refinement)
         flags = (1 if sub_pixel_refinement else 0) | (2 if outlier_rejection else 0)
