@@ -495,6 +495,7 @@ __global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
 #define WF5_TWA (7 * 64)
 #define WF5_TWB (8 * 7)
 #define WF5_TWK 128
+#define WF5_ROWS_PER_WG 32  // rounds of 8 rows: wave wv takes rows 2 wv and 2 wv + 1 of a round
 
 __device__ __forceinline__ wf2 wf5_ld2(const float* p) {  // 4-byte aligned 8-byte load
   wf2 v;
@@ -578,8 +579,9 @@ __global__ __launch_bounds__(256) void xc_rows_fwd_wave512(
   const float* base = src + job_off[job];
   cfloat* outa = T1a + (int64_t)job * g.nkx * g.ny;
   cfloat* outb = DUAL ? T1b + (int64_t)job * g.nkx * g.ny : nullptr;
-  const int r16 = grp * 16;
-  const int nrows = g.ny - r16 >= 16 ? 4 : (g.ny - r16 >= 8 ? 2 : 0);  // ny % 8 == 0
+  const int r16 = grp * WF5_ROWS_PER_WG;
+  const int rounds = min(WF5_ROWS_PER_WG / 8, (g.ny - r16) / 8);  // ny % 8 == 0
+  const int nrows = rounds > 0 ? 2 * rounds : 0;
   const int xlo = g.x0, xhi = g.x1 - 2;  // both even: a pair of samples is in or out as a whole
   __syncthreads();
   wf2 Xae[2], Xbe[2];  // bins of the even row of the current pair
@@ -591,21 +593,35 @@ __global__ __launch_bounds__(256) void xc_rows_fwd_wave512(
     asm volatile("" : "+v"(tl));  // per-row addresses are re-derived, not carried (registers)
     const float* row = base + (int64_t)y * row_stride;
     const float* mrow = mask + (int64_t)y * g.W;
-    wf2 A[8], Bv[8];
+    wf2 A[8], Bv[8], mk[8];
 #pragma unroll
-    for (int n1 = 0; n1 < 8; ++n1) {
+    for (int n1 = 0; n1 < 8; ++n1) {  // all sixteen loads in flight before anything is used
       const int x = 128 * n1 + 2 * tl;
-      const wf2 px = wf5_ld2(row + min(max(x, xlo), xhi));  // outside the support: mask == 0
-      const wf2 m = *reinterpret_cast<const wf2*>(mrow + x);
-      const wf2 a = (px - mean) * rstd;
-      wf2 ma = m;
-      for (int e = 1; e < ea; ++e) ma *= m;
-      A[n1] = a * ma;
-      if (DUAL) {
-        wf2 mb = m;
-        for (int e = 1; e < eb; ++e) mb *= m;
-        Bv[n1] = a * mb;
+      A[n1] = wf5_ld2(row + min(max(x, xlo), xhi));  // outside the support: mask == 0
+      mk[n1] = *reinterpret_cast<const wf2*>(mrow + x);
+    }
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) A[n1] = (A[n1] - mean) * rstd;
+    {  // mask^ea and mask^eb: wave-uniform trip counts, kept out of the load loop
+      wf2 pw[8];
+#pragma unroll
+      for (int n1 = 0; n1 < 8; ++n1) pw[n1] = mk[n1];
+      for (int e = 1; e < (DUAL ? eb : ea); ++e) {
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) pw[n1] *= mk[n1];
       }
+      if (DUAL) {
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) Bv[n1] = A[n1] * pw[n1];
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) pw[n1] = mk[n1];
+        for (int e = 1; e < ea; ++e) {
+#pragma unroll
+          for (int n1 = 0; n1 < 8; ++n1) pw[n1] *= mk[n1];
+        }
+      }
+#pragma unroll
+      for (int n1 = 0; n1 < 8; ++n1) A[n1] = A[n1] * pw[n1];
     }
     wf2 Xa[2], Xb[2];
     wf5_fft(A, tl, slab, twA, twB, twK, Xa);
@@ -1235,7 +1251,7 @@ int mc_xc_rows_forward_dual(const float* src, const int64_t* job_off, int64_t ro
     return MC_ERR_ARG;
   if (g.W != 2 * WF5_N || g.nkx > 128 || (g.ny % 8) || (reinterpret_cast<uintptr_t>(mask) & 7))
     return MC_ERR_UNSUPPORTED;
-  dim3 grid(njobs, (g.ny + 15) / 16);
+  dim3 grid(njobs, (g.ny + WF5_ROWS_PER_WG - 1) / WF5_ROWS_PER_WG);
   if (expo_b)
     hipLaunchKernelGGL(xc_rows_fwd_wave512<true>, grid, dim3(256), 0, (hipStream_t)stream, src, job_off,
                        row_stride, expo_a, expo_b, mask, mean_rstd, (cfloat*)T1a, (cfloat*)T1b,
