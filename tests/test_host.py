@@ -313,3 +313,25 @@ def test_deformation_field_csv_round_trip_and_wire_format(tmp_path):
     assert gaps[0, 0, 0, 0] == 0.25 and gaps[1, 1, 0, 1] == -2.0 and gaps[0, 1, 0, 0] == 0.0
     with pytest.raises(ValueError):
         m.write_deformation_field_to_csv(torch.zeros(3, 2, 2), p)
+
+
+@pytest.mark.parametrize("src", ["host_wave_fft.cpp", "host_wave_fft512.cpp"])
+def test_wave_fft_index_algebra_on_the_host(tmp_path, src):
+    """csrc/mc_wave_fft.h is written __host__ __device__: the lane ownership, slab addressing,
+    pruned butterflies and in-lane / lane-permute real-FFT unpack of both wave transforms
+    (2048 and 512 points) are executed lane by lane on the CPU and compared with a
+    double-precision DFT.  Needs clang++ (ext_vector_type); the ROCm one is used."""
+    import shutil
+    import subprocess
+
+    cxx = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(cxx):
+        cxx = shutil.which("clang++")
+    if not cxx:
+        pytest.skip("no clang++ on this machine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "a.out"
+    subprocess.run([cxx, "-O1", "-std=c++17", "-I", os.path.join(root, "torch_motion_correction_amd", "csrc"),
+                    os.path.join(root, "tests", src), "-o", str(exe), "-lm"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    assert out.strip().endswith("OK"), out
