@@ -6,10 +6,10 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out/round
 python3 bench.py --steps 10 --warmup 3 > gpurun_out/round/bench_default.log 2>&1 || exit 1
 tail -1 gpurun_out/round/bench_default.log > gpurun_out/round/bench_line.json
-python3 bench.py --steps 10 --warmup 3 --no-overlap --no-cpu-baseline > gpurun_out/round/bench_seq.log 2>&1 || exit 1
+python3 bench.py --steps 10 --warmup 3 --no-overlap --no-cpu-baseline --no-secondary > gpurun_out/round/bench_seq.log 2>&1 || exit 1
 tail -1 gpurun_out/round/bench_seq.log > gpurun_out/round/bench_line_no_overlap.json
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/round/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/round/stats.log 2>&1 || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/round/stats_seq -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-overlap > gpurun_out/round/stats_seq.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/round/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > gpurun_out/round/stats.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/round/stats_seq -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-overlap > gpurun_out/round/stats_seq.log 2>&1 || exit 1
 bash scripts/gpu_traffic.sh round/traffic > gpurun_out/round/traffic.txt 2>&1 || exit 1
 cat gpurun_out/round/traffic.txt | tail -16
 cut -c1-300 gpurun_out/round/bench_line.json

@@ -6,7 +6,7 @@ tag=${1:-traffic}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/${tag}_$c -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-overlap > gpurun_out/${tag}_$c.log 2>&1 || exit 1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/${tag}_$c -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary --no-overlap > gpurun_out/${tag}_$c.log 2>&1 || exit 1
 done
 python3 - gpurun_out/${tag}_FETCH_SIZE gpurun_out/${tag}_WRITE_SIZE <<'PY'
 import csv, sys, glob, collections, json
