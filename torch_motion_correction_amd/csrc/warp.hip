@@ -352,23 +352,26 @@ __global__ __launch_bounds__(WARP_TX* WARP_TY) void warp_main(WarpArgs a) {
 #define RIGID_NQ (RIGID_TROWS * RIGID_QUADS)           // quads per tile (2448)
 #define RIGID_QPT ((RIGID_NQ + 255) / 256)             // quads per thread (10)
 
-// pass 0: S[f][axis] = min_p floor(u(p)) - p
-__global__ void rigid_base(const float* __restrict__ shifts, int nframes, int h, int w,
-                           int* __restrict__ S) {
-  const int f = blockIdx.y, axis = blockIdx.z;
+// pass 0: S[f][axis] = min_p floor(u(p)) - p.  One workgroup per (frame, axis): no atomics,
+// no pre-set of S (80 words fought over by 1280 workgroups cost 20 us in atomics alone).
+__global__ __launch_bounds__(256) void rigid_base(const float* __restrict__ shifts, int nframes, int h,
+                                                  int w, int* __restrict__ S) {
+  const int f = blockIdx.x, axis = blockIdx.y;
   const int n = axis == 0 ? h : w;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const float s = shifts[2 * f + axis];
+  // clamp the (finite) offset so absurd shifts cannot overflow
+  const float lim = 3.0f * (float)n + 16.f;
   int di = 0x7fffffff;
-  if (p < n) {
-    const float s = shifts[2 * f + axis];
+  for (int p = threadIdx.x; p < n; p += 256) {
     const float u = grid_chain((float)p + s, (float)n);
     const float d = floorf(u) - (float)p;
-    // clamp the (finite) offset so absurd shifts cannot overflow
-    const float lim = 3.0f * (float)n + 16.f;
-    di = (int)fminf(fmaxf(d, -lim), lim);
+    di = min(di, (int)fminf(fmaxf(d, -lim), lim));
   }
-  for (int off = 32; off > 0; off >>= 1) di = min(di, __shfl_xor(di, off));  // one atomic per wave
-  if ((threadIdx.x & 63) == 0 && di != 0x7fffffff) atomicMin(&S[2 * f + axis], di);
+  for (int off = 32; off > 0; off >>= 1) di = min(di, __shfl_xor(di, off));
+  __shared__ int part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = di;
+  __syncthreads();
+  if (threadIdx.x == 0) S[2 * f + axis] = min(min(part[0], part[1]), min(part[2], part[3]));
 }
 
 // pass 1: W[f][axis][k][p], k = 0..4
@@ -1299,11 +1302,9 @@ int mc_warp_rigid(const float* frames, int nframes, int h, int w, const float* s
   float* Wy = scratch;
   float* Wx = Wy + (int64_t)nframes * 5 * h;
   int* S = reinterpret_cast<int*>(Wx + (int64_t)nframes * 5 * w);
-  hipError_t e = hipMemsetAsync(S, 0x7f, sizeof(int) * 2 * nframes, s);
-  if (e != hipSuccess) return (int)e;
   const int n = h > w ? h : w;
   dim3 tg((n + 255) / 256, nframes, 2);
-  hipLaunchKernelGGL(rigid_base, tg, dim3(256), 0, s, shifts_px, nframes, h, w, S);
+  hipLaunchKernelGGL(rigid_base, dim3(nframes, 2), dim3(256), 0, s, shifts_px, nframes, h, w, S);
   hipLaunchKernelGGL(rigid_weights, tg, dim3(256), 0, s, shifts_px, nframes, h, w, S, Wy, Wx);
   RigidArgs a;
   a.frames = frames; a.nframes = nframes; a.h = h; a.w = w; a.S = S; a.Wy = Wy; a.Wx = Wx;

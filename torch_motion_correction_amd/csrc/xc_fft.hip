@@ -831,6 +831,15 @@ __global__ __launch_bounds__(MC_WG) void xc_cols_inv_near(
   }
 }
 
+// best[p] = order(-inf), gate = 0, bounds = 0 in one launch
+__global__ void xc_search_init(int* __restrict__ best, int* __restrict__ gate, float* __restrict__ bounds,
+                               int npairs, int nbounds) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nbounds) bounds[i] = 0.f;
+  if (i < npairs) best[i] = (int)0x807fffffu;  // float_order(-INFINITY) = 0xff800000 ^ 0x7fffffff
+  if (i == 0) gate[0] = 0;
+}
+
 // After the near-window phase: a far row group must be evaluated iff its bound can reach
 // the maximum attained so far.  Initialises the far groups' candidates and raises
 // need_full[0] when any such group exists.
@@ -1428,16 +1437,8 @@ int mc_xc_correlate_argmax(const void* S_cur, const int* cur_idx, const void* S_
   int* best = part_idx + (int64_t)npairs * ngrp;  // npairs running maxima, then the gate word
   int* gate = best + npairs;
   float* bounds = part_val + (int64_t)npairs * ngrp;  // npairs * H row bounds
-  {
-    const float ninf = -INFINITY;
-    int pat;
-    memcpy(&pat, &ninf, 4);
-    pat = pat >= 0 ? pat : pat ^ 0x7fffffff;
-    hipError_t e = hipMemsetD32Async((hipDeviceptr_t)best, pat, npairs, st);
-    if (e == hipSuccess) e = hipMemsetAsync(gate, 0, sizeof(int), st);
-    if (e == hipSuccess) e = hipMemsetAsync(bounds, 0, sizeof(float) * (size_t)npairs * g.H, st);
-    if (e != hipSuccess) return (int)e;
-  }
+  hipLaunchKernelGGL(xc_search_init, dim3((npairs * g.H + 255) / 256), dim3(256), 0, st, best, gate, bounds,
+                     npairs, npairs * g.H);
   MC_DISPATCH_LOG(mc_ilog2(g.H), {
     if constexpr (L >= 10) {
       hipLaunchKernelGGL(xc_cols_inv_near<L>, dim3((g.nkx + XC_NEAR_COLS - 1) / XC_NEAR_COLS, npairs),
