@@ -94,6 +94,11 @@ int mc_xc_rows_forward_dual(const float* src, const int64_t* job_off, int64_t ro
                             const float* mean_rstd, void* T1a, void* T1b, const void* tw_row,
                             int njobs, const mc_xc_geom* geom, void* stream);
 
+/* Column-transform engine of K2 / the near-window K3: 0 = automatic (H == 4096 with at most
+ * 512 kept rows at either end of the spectrum -> register-resident radix-16 transform),
+ * 1 = always the radix-8 Stockham passes.  Process-wide; results agree to fp32 rounding. */
+int mc_xc_col_engine(int mode);
+
 /* Row-transform engine of K1: 0 = automatic (W == 4096, nkx <= 512, no per-job exponents,
  * 16-byte aligned src/mask and row_stride % 4 == 0 -> one wavefront per row, mc_wave_fft.h;
  * job_off[] must then be multiples of 4 floats, as whole-frame offsets f*h*w are),

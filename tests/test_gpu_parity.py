@@ -713,3 +713,33 @@ def test_wave512_patch_rows_match_workgroup_engine(dev):
         got, ref = got.cpu(), ref.cpu()
         assert torch.isfinite(got).all()
         assert float((got - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
+
+
+def test_radix16_column_engine_matches_stockham_columns(mc, dev):
+    """H = 4096 columns: the register-resident radix-16 transform (K2 with pruned outputs, the
+    near-window K3 with pruned inputs) against the radix-8 Stockham passes: filtered spectra,
+    and the arg-max search end to end (near window, bounds, device-side fallback)."""
+    from torch_motion_correction_amd import _lib, engine, plan
+    from torch_motion_correction_amd._lib import check
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(41)
+    base = torch.randn(4096 + 256, 4096 + 256, generator=g)
+    offs = [(0, 0), (5, -3), (-2, 7), (100, -90)]  # the last one lies beyond the near window
+    img = torch.stack([base[128 - dy : 128 - dy + 4096, 128 - dx : 128 - dx + 4096] for dy, dx in offs])
+    img = (img + 0.5 * torch.randn(len(offs), 4096, 4096, generator=g)).to(dev)
+    pl = plan.get_xc_plan(4096, 4096, 1.0, 500.0, (300, 10), dev)
+    res = {}
+    try:
+        for mode in (1, 0):
+            check(lib.mc_xc_col_engine(mode), "mc_xc_col_engine")
+            S = engine._global_spectra(img, pl)
+            f = mc.estimate_global_motion(img, 1.0, reference_frame=0)
+            res[mode] = (S.cpu(), f.cpu())
+    finally:
+        lib.mc_xc_col_engine(0)
+    assert torch.isfinite(res[0][0]).all()
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 1e-5 * float(res[1][0].abs().max())
+    assert torch.equal(res[0][1], res[1][1])
+    assert res[0][1][0, :, 0, 0].tolist() == [float(o[0]) for o in offs]
+    assert res[0][1][1, :, 0, 0].tolist() == [float(o[1]) for o in offs]

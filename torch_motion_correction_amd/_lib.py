@@ -45,6 +45,7 @@ SIGNATURES = {
     "mc_normalize": [vp, vp, i64, vp, vp],
     "mc_xc_rows_lds_bytes": [GP],
     "mc_xc_row_engine": [i32],
+    "mc_xc_col_engine": [i32],
     "mc_xc_rows_forward": [vp, vp, i64, vp, vp, vp, vp, vp, i32, GP, vp],
     "mc_xc_rows_forward_dual": [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, GP, vp],
     "mc_xc_rows_forward_stats": [vp, vp, i64, vp, vp, vp, vp, i32, GP, i32, i32, i32, i32, vp, vp, vp, vp],

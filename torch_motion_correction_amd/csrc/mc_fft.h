@@ -345,3 +345,84 @@ __device__ __forceinline__ void wg_bluestein(cfloat* line, int tid, const cfloat
   };
   wg_fft_inplace<M, +1>(line, tid, tw_m, 1, in2, out2);
 }
+
+// =====================================================================================
+// 4096-point transform by one 256-thread workgroup, sixteen values per thread in registers:
+// N = 16 x 16 x 16, three register-resident radix-16 passes, two exchanges through ONE
+// 32 KiB LDS line (4 barriers per transform instead of the 7 of the radix-8 Stockham
+// passes above).  n = 256 n1 + 16 n2 + n3,  k = k1 + 16 k2 + 256 k3:
+//   pass A  thread q = 16 n2 + n3 = tid:  radix 16 over n1, twiddle W_4096^{q k1}
+//   pass B  thread (k1, n3) = (tid >> 4, tid & 15): radix 16 over n2, twiddle W_256^{n3 k2}
+//   pass C  thread c = k1 + 16 k2 = tid:  radix 16 over n3, output k = c + 256 k3
+// LDS addresses (complex index), conflict-free for 8-byte writes (16-lane groups) and reads
+// (32-lane groups):
+//   exchange 1: (k1, q)       at k1 * 256 + (q ^ (16 * (k1 & 1)))
+//   exchange 2: (k1, k2, n3)  at k1 * 256 + k2 * 16 + (n3 ^ k1)
+// Pruning is resolved at compile time: with IN_KEEP < 8 only the inputs n1 in [0, IN_KEEP) and
+// [16 - IN_KEEP, 16) are fetched (the others are literal zeros: band-limited spectra), with
+// OUT_KEEP < 8 only the outputs k3 in [0, OUT_KEEP) and [16 - OUT_KEEP, 16) are produced;
+// the dead butterfly arithmetic disappears.  DIR = +1 runs the forward kernel on conjugated
+// data.  load(n1, n) -> input n = 256 n1 + tid (n1 a compile-time constant after unrolling);
+// store(k, v) <- output k.  Every thread of
+// the workgroup must call it; `line` (4096 entries) must be free on entry and is free again
+// after a __syncthreads() on exit.  tw = exp(-2 pi i k / 4096), 4096 entries.
+// =====================================================================================
+#include "mc_wave_fft.h"
+
+template <int DIR, int IN_KEEP, int OUT_KEEP, typename Load, typename Store>
+__device__ __forceinline__ void wg_fft4096_r16(cfloat* line_c, int tid, const cfloat* __restrict__ tw,
+                                               Load load, Store store) {
+  wf2* line = reinterpret_cast<wf2*>(line_c);
+  auto cj = [](wf2 v) { return DIR > 0 ? wf2{v.x, -v.y} : v; };
+  auto twp = [&](int k) { return wf_from(tw[k]); };
+  wf2 a[16];
+  // ---- pass A
+#pragma unroll
+  for (int n1 = 0; n1 < 16; ++n1) {
+    if (n1 < IN_KEEP || n1 >= 16 - IN_KEEP) a[n1] = cj(wf_from(load(n1, 256 * n1 + tid)));
+    else a[n1] = wf2{0.f, 0.f};
+  }
+  wf_dft16(a);
+  {
+    const wf2 w1 = twp(tid), w2 = twp(2 * tid), w4 = twp(4 * tid), w8 = twp(8 * tid);  // exact bases
+    const wf2 w3 = wf_cmul(w2, w1), w5 = wf_cmul(w4, w1), w6 = wf_cmul(w4, w2), w7 = wf_cmul(w4, w3);
+    a[1] = wf_cmul(a[1], w1); a[2] = wf_cmul(a[2], w2); a[3] = wf_cmul(a[3], w3); a[4] = wf_cmul(a[4], w4);
+    a[5] = wf_cmul(a[5], w5); a[6] = wf_cmul(a[6], w6); a[7] = wf_cmul(a[7], w7); a[8] = wf_cmul(a[8], w8);
+    a[9] = wf_cmul(a[9], wf_cmul(w8, w1)); a[10] = wf_cmul(a[10], wf_cmul(w8, w2));
+    a[11] = wf_cmul(a[11], wf_cmul(w8, w3)); a[12] = wf_cmul(a[12], wf_cmul(w8, w4));
+    a[13] = wf_cmul(a[13], wf_cmul(w8, w5)); a[14] = wf_cmul(a[14], wf_cmul(w8, w6));
+    a[15] = wf_cmul(a[15], wf_cmul(w8, w7));
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) line[k1 * 256 + (tid ^ (16 * (k1 & 1)))] = a[k1];
+  __syncthreads();
+  // ---- pass B: (k1, n3) = (tid >> 4, tid & 15), entries (k1, q = 16 n2 + n3)
+  {
+    const int k1 = tid >> 4, n3 = tid & 15;
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) a[n2] = line[k1 * 256 + ((16 * n2 + n3) ^ (16 * (k1 & 1)))];
+    __syncthreads();  // everyone has read exchange 1 before exchange 2 overwrites the line
+    wf_dft16(a);
+    const wf2 w1 = twp(16 * n3), w2 = twp(32 * n3), w4 = twp(64 * n3), w8 = twp(128 * n3);
+    const wf2 w3 = wf_cmul(w2, w1), w5 = wf_cmul(w4, w1), w6 = wf_cmul(w4, w2), w7 = wf_cmul(w4, w3);
+    a[1] = wf_cmul(a[1], w1); a[2] = wf_cmul(a[2], w2); a[3] = wf_cmul(a[3], w3); a[4] = wf_cmul(a[4], w4);
+    a[5] = wf_cmul(a[5], w5); a[6] = wf_cmul(a[6], w6); a[7] = wf_cmul(a[7], w7); a[8] = wf_cmul(a[8], w8);
+    a[9] = wf_cmul(a[9], wf_cmul(w8, w1)); a[10] = wf_cmul(a[10], wf_cmul(w8, w2));
+    a[11] = wf_cmul(a[11], wf_cmul(w8, w3)); a[12] = wf_cmul(a[12], wf_cmul(w8, w4));
+    a[13] = wf_cmul(a[13], wf_cmul(w8, w5)); a[14] = wf_cmul(a[14], wf_cmul(w8, w6));
+    a[15] = wf_cmul(a[15], wf_cmul(w8, w7));
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) line[k1 * 256 + k2 * 16 + (n3 ^ k1)] = a[k2];
+  }
+  __syncthreads();
+  // ---- pass C: c = k1 + 16 k2 = tid
+  {
+    const int k1 = tid & 15, k2 = tid >> 4;
+#pragma unroll
+    for (int n3 = 0; n3 < 16; ++n3) a[n3] = line[k1 * 256 + k2 * 16 + (n3 ^ k1)];
+    wf_dft16(a);
+#pragma unroll
+    for (int k3 = 0; k3 < 16; ++k3)
+      if (k3 < OUT_KEEP || k3 >= 16 - OUT_KEEP) store(tid + 256 * k3, wf_to(cj(a[k3])));
+  }
+}

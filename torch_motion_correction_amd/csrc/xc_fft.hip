@@ -680,7 +680,10 @@ __global__ void xc_stats_finalize(const double* __restrict__ acc_slots, double c
 // ------------------------------------------------------------------ K2: columns forward
 // fix (optional): {dmean, rstd} and Mhat = pruned spectrum of the mask: the spectrum of
 // ((x - m0) - dmean) * rstd * mask is (Y - dmean * Mhat) * rstd by linearity.
-template <int LOGH>
+#define XC_FWD_COLS 1  // columns per workgroup in the radix-16 K2 (4 with prefetch measured slower: 170 vs 154 us)
+// R16 (H = 4096, kyp and kyn <= 512): the register-resident radix-16 transform of mc_fft.h
+// with the unwanted output rows pruned at compile time.
+template <int LOGH, bool R16 = false>
 __global__ __launch_bounds__(MC_WG) void xc_cols_fwd(const cfloat* __restrict__ T1,
                                                      const float* __restrict__ filt,
                                                      cfloat* __restrict__ S,
@@ -688,7 +691,7 @@ __global__ __launch_bounds__(MC_WG) void xc_cols_fwd(const cfloat* __restrict__ 
                                                      const float* __restrict__ fix,
                                                      const cfloat* __restrict__ Mhat) {
   constexpr int H = 1 << LOGH;
-  __shared__ __attribute__((aligned(16))) cfloat line[lds_len(H)];
+  __shared__ __attribute__((aligned(16))) cfloat line[R16 ? H : lds_len(H)];  // radix 16: unpadded, 5 workgroups / CU
   const int tid = threadIdx.x;
   const int kx = blockIdx.x, job = blockIdx.y;
   const cfloat* col = T1 + ((int64_t)job * g.nkx + kx) * g.ny;
@@ -713,7 +716,51 @@ __global__ __launch_bounds__(MC_WG) void xc_cols_fwd(const cfloat* __restrict__ 
       out[kyi] = f ? cscale(v, f[kyi]) : v;
     }
   };
-  wg_fft<H, -1>(line, tid, tw_col, 1, load, store);
+  if constexpr (R16) {
+    // XC_FWD_COLS consecutive kx columns per workgroup (blockIdx.x counts column groups): the next
+    // column's samples are in flight (registers) while the current one is transformed
+    const int kx0 = blockIdx.x * XC_FWD_COLS;
+    auto fetch = [&](int kxc, cfloat (&v)[16], int tq) {
+      const cfloat* c = T1 + ((int64_t)job * g.nkx + kxc) * g.ny;
+#pragma unroll
+      for (int n1 = 0; n1 < 16; ++n1) {
+        const int yy = 256 * n1 + tq - g.y0;
+        v[n1] = (yy >= 0 && yy < g.ny) ? c[yy] : cmake(0.f, 0.f);
+      }
+    };
+    cfloat curv[16], nxtv[16];
+    fetch(kx0 < g.nkx ? kx0 : g.nkx - 1, curv, tid);
+#pragma unroll 1
+    for (int cc = 0; cc < XC_FWD_COLS; ++cc) {
+      const int kxc = kx0 + cc;
+      if (kxc >= g.nkx) break;  // workgroup-uniform
+      int tcol = tid;  // opaque per column: nothing derived from it is hoisted (registers)
+      asm volatile("" : "+v"(tcol));
+      if (cc + 1 < XC_FWD_COLS && kxc + 1 < g.nkx) fetch(kxc + 1, nxtv, tcol);
+      cfloat* outc = S + ((int64_t)job * g.nkx + kxc) * nky;
+      const float* fc = filt ? filt + (int64_t)kxc * nky : nullptr;
+      const cfloat* mhc = fix ? Mhat + (int64_t)kxc * nky : nullptr;
+      auto loadr = [&](int n1, int) { return curv[n1]; };
+      auto storer = [&](int ky, cfloat v) {
+        int kyi = -1;
+        if (ky < g.kyp) kyi = ky;
+        else if (ky >= H - g.kyn) kyi = ky - (H - g.kyn) + g.kyp;
+        if (kyi >= 0) {
+          if (fix) {
+            const cfloat m = mhc[kyi];
+            v = cmake((v.x - dmean * m.x) * rstd, (v.y - dmean * m.y) * rstd);
+          }
+          outc[kyi] = fc ? cscale(v, fc[kyi]) : v;
+        }
+      };
+      wg_fft4096_r16<-1, 8, 2>(line, tcol, tw_col, loadr, storer);
+      __syncthreads();
+#pragma unroll
+      for (int n1 = 0; n1 < 16; ++n1) curv[n1] = nxtv[n1];
+    }
+  } else {
+    wg_fft<H, -1>(line, tid, tw_col, 1, load, store);
+  }
 }
 
 // ------------------------------------------------------------------ K3: columns inverse
@@ -773,13 +820,13 @@ __global__ __launch_bounds__(MC_WG) void xc_cols_inv(
 // only ever materialised (xc_cols_inv, gated by `need_full`) when some far row's bound
 // reaches the maximum found in the near window.
 #define XC_NEAR_COLS 8
-template <int LOGH>
+template <int LOGH, bool R16 = false>
 __global__ __launch_bounds__(MC_WG) void xc_cols_inv_near(
     const cfloat* __restrict__ S_cur, const int* __restrict__ cur_idx,
     const cfloat* __restrict__ S_ref, const int* __restrict__ ref_idx, cfloat* __restrict__ T2n,
     float* __restrict__ bounds, const cfloat* __restrict__ tw_col, float scale, XcGeom g, int nnear) {
   constexpr int H = 1 << LOGH;
-  __shared__ __attribute__((aligned(16))) cfloat line[lds_len(H)];
+  __shared__ __attribute__((aligned(16))) cfloat line[R16 ? H : lds_len(H)];
   constexpr int NOUT = H / MC_WG;  // rows per thread in the last pass (H >= 1024: all threads busy)
   const int tid = threadIdx.x;
   const int p = blockIdx.y;
@@ -802,6 +849,7 @@ __global__ __launch_bounds__(MC_WG) void xc_cols_inv_near(
       if (kyi < 0) return cmake(0.f, 0.f);
       return cscale(cmulc(ref[kyi], cur[kyi]), scale);
     };
+    auto load16 = [&](int, int ky) { return load(ky); };
     int c = 0;
     auto store = [&](int y, cfloat v) {
       const int yn = y < nnear ? y : y - (H - 2 * nnear);  // position in the near window
@@ -814,12 +862,16 @@ __global__ __launch_bounds__(MC_WG) void xc_cols_inv_near(
     // hoisted out of the column loop into ~90 registers (one workgroup less per CU)
     int tcol = tid;
     asm volatile("" : "+v"(tcol));
-    wg_fft<H, +1>(line, tcol, tw_col, 1, load, store);
+    if constexpr (R16) wg_fft4096_r16<+1, 2, 8>(line, tcol, tw_col, load16, store);
+    else wg_fft<H, +1>(line, tcol, tw_col, 1, load, store);
     __syncthreads();  // the next column's first pass overwrites the line
   }
   // rows of the last pass (fft_pass with NS * R == H): y = tid + it * MC_WG + m * (H / R), in
   // the order it-major, m-minor
-  {
+  if constexpr (R16) {  // wg_fft4096_r16 stores y = tid + 256 k3 in the order k3 = 0..15
+#pragma unroll
+    for (int k3 = 0; k3 < 16; ++k3) atomicAdd(&bounds[(int64_t)p * H + tid + 256 * k3], acc[k3]);
+  } else {
     constexpr int R = (H >= 4096) ? 8 : (H == 2048 ? 4 : 2);  // last radix of FftPlan<H>: 8 8 8 {8,4,2}
     constexpr int NB = H / R, IT = NB / MC_WG;
     static_assert(IT * R == NOUT, "row ownership of the last pass");
@@ -1155,6 +1207,7 @@ static int geom_from(const mc_xc_geom* q, XcGeom* g, bool rows_pow2 = true, bool
 
 // mc_xc_row_engine(): 0 = automatic (wave-per-row kernel whenever the shape fits),
 // 1 = always the workgroup-per-row kernels (A/B timing and cross-checks of the engines).
+static int g_col_engine = 0;  // mc_xc_col_engine(): 0 = automatic, 1 = always the radix-8 Stockham columns
 static int g_row_engine = 0;
 static int g_wave_extra_lds = 0;  // tuning hook: dynamic LDS padding to cap workgroups per CU
 static int g_wave_prefetch = -1;  // tuning hook (mc_xc_row_engine(2 + depth)); -1 = default
@@ -1174,6 +1227,12 @@ static size_t rows_lds_bytes(int N, const XcGeom& g) {
 }
 
 extern "C" {
+
+int mc_xc_col_engine(int mode) {
+  if (mode < 0 || mode > 1) return MC_ERR_ARG;
+  g_col_engine = mode;
+  return MC_OK;
+}
 
 int mc_xc_row_engine(int mode) {
   if (mode >= 100) {  // tuning hook: 100 + KiB of dynamic LDS padding for the wave kernel
@@ -1313,6 +1372,13 @@ int mc_xc_cols_forward_fix(const void* T1, const float* filt, void* S, const voi
   if (rc) return rc;
   if (!T1 || !S || !tw_col || njobs < 1 || (fix && !Mhat)) return MC_ERR_ARG;
   dim3 grid(g.nkx, njobs);
+  if (g.H == 4096 && g.kyp <= 512 && g.kyn <= 512 && g_col_engine == 0) {
+    hipLaunchKernelGGL((xc_cols_fwd<12, true>), dim3((g.nkx + XC_FWD_COLS - 1) / XC_FWD_COLS, njobs),
+                       dim3(MC_WG), 0, (hipStream_t)stream,
+                       (const cfloat*)T1, filt, (cfloat*)S, (const cfloat*)tw_col, g, fix,
+                       (const cfloat*)Mhat);
+    return mc_check_launch();
+  }
   MC_DISPATCH_LOG(mc_ilog2(g.H), {
     hipLaunchKernelGGL(xc_cols_fwd<L>, grid, dim3(MC_WG), 0, (hipStream_t)stream,
                        (const cfloat*)T1, filt, (cfloat*)S, (const cfloat*)tw_col, g, fix,
@@ -1439,6 +1505,11 @@ int mc_xc_correlate_argmax(const void* S_cur, const int* cur_idx, const void* S_
   float* bounds = part_val + (int64_t)npairs * ngrp;  // npairs * H row bounds
   hipLaunchKernelGGL(xc_search_init, dim3((npairs * g.H + 255) / 256), dim3(256), 0, st, best, gate, bounds,
                      npairs, npairs * g.H);
+  if (g.H == 4096 && g.kyp <= 512 && g.kyn <= 512 && g_col_engine == 0) {
+    hipLaunchKernelGGL((xc_cols_inv_near<12, true>), dim3((g.nkx + XC_NEAR_COLS - 1) / XC_NEAR_COLS, npairs),
+                       dim3(MC_WG), 0, st, (const cfloat*)S_cur, cur_idx, (const cfloat*)S_ref, ref_idx,
+                       (cfloat*)T2_near, bounds, (const cfloat*)tw_col, scale, g, nnear);
+  } else
   MC_DISPATCH_LOG(mc_ilog2(g.H), {
     if constexpr (L >= 10) {
       hipLaunchKernelGGL(xc_cols_inv_near<L>, dim3((g.nkx + XC_NEAR_COLS - 1) / XC_NEAR_COLS, npairs),
