@@ -19,9 +19,7 @@ st = stream_ptr(dev)
 def k1():
     check(lib.mc_xc_rows_forward_stats(ptr(stack), ptr(off), w, ptr(pl.mask), ptr(m0), ptr(T1), ptr(pl.tw_row), t, gm,
                                        hl, hu, wl, wu, ptr(acc), ptr(fix), ptr(out3), st), "k1")
-modes = [int(a) for a in sys.argv[1:] if int(a) < 100] or [0]
-for a in sys.argv[1:]:
-    if int(a) >= 100: check(lib.mc_xc_row_engine(int(a)), 'pad')
+modes = [int(a) for a in sys.argv[1:]] or [0, 1]  # 0 = wave-per-row engine, 1 = workgroup-per-row
 for rep in range(2):
     for mode in modes:
         check(lib.mc_xc_row_engine(mode), "engine")

@@ -1209,8 +1209,6 @@ static int geom_from(const mc_xc_geom* q, XcGeom* g, bool rows_pow2 = true, bool
 // 1 = always the workgroup-per-row kernels (A/B timing and cross-checks of the engines).
 static int g_col_engine = 0;  // mc_xc_col_engine(): 0 = automatic, 1 = always the radix-8 Stockham columns
 static int g_row_engine = 0;
-static int g_wave_extra_lds = 0;  // tuning hook: dynamic LDS padding to cap workgroups per CU
-static int g_wave_prefetch = -1;  // tuning hook (mc_xc_row_engine(2 + depth)); -1 = default
 static bool mc_force_wg_rows() { return g_row_engine == 1; }
 
 // The wave-per-row kernel reads samples and mask rows with 16-byte loads.  job_off[] lives
@@ -1235,13 +1233,8 @@ int mc_xc_col_engine(int mode) {
 }
 
 int mc_xc_row_engine(int mode) {
-  if (mode >= 100) {  // tuning hook: 100 + KiB of dynamic LDS padding for the wave kernel
-    g_wave_extra_lds = (mode - 100) * 1024;
-    return MC_OK;
-  }
-  if (mode < 0 || mode > 4) return MC_ERR_ARG;
-  g_row_engine = mode == 1 ? 1 : 0;
-  g_wave_prefetch = mode >= 2 ? mode - 2 : -1;
+  if (mode < 0 || mode > 1) return MC_ERR_ARG;
+  g_row_engine = mode;
   return MC_OK;
 }
 
@@ -1269,7 +1262,7 @@ static int rows_forward_impl(const float* src, const int64_t* job_off, int64_t r
     const int ngroups = (g.ny + WF_ROWS_PER_WG - 1) / WF_ROWS_PER_WG;
     dim3 grid((ngroups + 7) / 8 * 8, njobs);  // linear id = x + gridDim.x * y, decoded in the kernel
 #define MC_WAVE_LAUNCH(KEEP, ST, LO, HI, CL, PF)                                                  \
-  hipLaunchKernelGGL((xc_rows_fwd_wave<KEEP, ST, LO, HI, CL, PF>), grid, dim3(256), g_wave_extra_lds,            \
+  hipLaunchKernelGGL((xc_rows_fwd_wave<KEEP, ST, LO, HI, CL, PF>), grid, dim3(256), 0,            \
                      (hipStream_t)stream, src, job_off, row_stride, mask, mean_rstd, (cfloat*)T1,   \
                      (const cfloat*)tw_row, g, b, stats_acc)
 #define MC_WAVE_PICK(KEEP, ST)                                                              \
@@ -1279,13 +1272,6 @@ static int rows_forward_impl(const float* src, const int64_t* job_off, int64_t r
     else                                                                                    \
       MC_WAVE_LAUNCH(KEEP, ST, 0, 16, true, WF_PREFETCH_DEFAULT);                           \
   } while (0)
-    if (g_wave_prefetch >= 0 && g.nkx > 256 && stats_acc && g.x0 >= 256 && g.x0 <= 512 && g.x1 >= 3584 &&
-        g.x1 <= 3840) {  // tuning hook: prefetch depth of the benchmark variant
-      if (g_wave_prefetch == 0) MC_WAVE_LAUNCH(2, true, 1, 15, false, 0);
-      else if (g_wave_prefetch == 1) MC_WAVE_LAUNCH(2, true, 1, 15, false, 1);
-      else MC_WAVE_LAUNCH(2, true, 1, 15, false, 2);
-      return mc_check_launch();
-    }
     if (g.nkx <= 256) {
       if (stats_acc) MC_WAVE_PICK(1, true); else MC_WAVE_PICK(1, false);
     } else {
