@@ -95,7 +95,8 @@ int mc_xc_rows_forward_dual(const float* src, const int64_t* job_off, int64_t ro
                             int njobs, const mc_xc_geom* geom, void* stream);
 
 /* Column-transform engine of K2 / the near-window K3: 0 = automatic (H == 4096 with at most
- * 512 kept rows at either end of the spectrum -> register-resident radix-16 transform),
+ * 512 kept rows at either end of the spectrum -> register-resident radix-16 transform;
+ * H == 1024 with at most 128 -> one wavefront per column, mc_wave_fft.h),
  * 1 = always the radix-8 Stockham passes.  Process-wide; results agree to fp32 rounding. */
 int mc_xc_col_engine(int mode);
 

@@ -743,3 +743,40 @@ def test_radix16_column_engine_matches_stockham_columns(mc, dev):
     assert torch.equal(res[0][1], res[1][1])
     assert res[0][1][0, :, 0, 0].tolist() == [float(o[0]) for o in offs]
     assert res[0][1][1, :, 0, 0].tolist() == [float(o[1]) for o in offs]
+
+
+def test_wave1024_patch_columns_match_workgroup_engine(dev):
+    """H = 1024 columns (patches): one wavefront per column (K2 with pruned outputs, K3 with
+    pruned inputs) against the workgroup-per-column Stockham kernels."""
+    from torch_motion_correction_amd import _lib, engine, plan
+    from torch_motion_correction_amd._lib import check, ptr, stream_ptr
+
+    lib = _lib.load()
+    p, h, w = 1024, 1300, 2100
+    g = torch.Generator().manual_seed(10)
+    img = (torch.randn(3, h, w, generator=g) * 0.9 + 2.0).to(dev)
+    pl = plan.get_xc_plan(p, p, 1.0, 500.0, (300, 10), dev)
+    gm = pl.geom
+    assert gm.H == 1024 and gm.kyp <= 128 and gm.kyn <= 128
+    off = torch.tensor([0, 201 * w + 77, h * w + 100 * w + 1000, 2 * h * w + 276 * w + 1076], dtype=torch.int64,
+                       device=dev)
+    ex = torch.tensor([1, 2, 1, 2], dtype=torch.int32, device=dev)
+    stats = torch.tensor([2.0, 1.1], device=dev)
+    n = int(off.numel())
+    cur = torch.arange(n, dtype=torch.int32, device=dev)
+    ref = torch.tensor([1, 0, 3, 2], dtype=torch.int32, device=dev)
+    st = stream_ptr(dev)
+    res = {}
+    try:
+        for mode in (1, 0):
+            check(lib.mc_xc_col_engine(mode), "mc_xc_col_engine")
+            S = engine._forward_spectra(img, off, w, ex, pl, stats, min_expo=1)
+            T2 = torch.zeros((n, gm.nkx, gm.H, 2), device=dev)
+            check(lib.mc_xc_cols_inverse(ptr(S), ptr(cur), ptr(S), ptr(ref), ptr(T2), ptr(pl.tw_col),
+                                         1.0 / (p * p), n, gm, st), "mc_xc_cols_inverse")
+            res[mode] = (S.cpu(), T2.cpu())
+    finally:
+        lib.mc_xc_col_engine(0)
+    for a, b in zip(res[0], res[1]):
+        assert torch.isfinite(a).all()
+        assert float((a - b).abs().max()) <= 5e-6 * float(b.abs().max())

@@ -315,11 +315,11 @@ def test_deformation_field_csv_round_trip_and_wire_format(tmp_path):
         m.write_deformation_field_to_csv(torch.zeros(3, 2, 2), p)
 
 
-@pytest.mark.parametrize("src", ["host_wave_fft.cpp", "host_wave_fft512.cpp"])
+@pytest.mark.parametrize("src", ["host_wave_fft.cpp", "host_wave_fft512.cpp", "host_wave_fft1024.cpp"])
 def test_wave_fft_index_algebra_on_the_host(tmp_path, src):
     """csrc/mc_wave_fft.h is written __host__ __device__: the lane ownership, slab addressing,
     pruned butterflies and in-lane / lane-permute real-FFT unpack of both wave transforms
-    (2048 and 512 points) are executed lane by lane on the CPU and compared with a
+    (2048- and 512-point rows, 1024-point columns) are executed lane by lane on the CPU and compared with a
     double-precision DFT.  Needs clang++ (ext_vector_type); the ROCm one is used."""
     import shutil
     import subprocess

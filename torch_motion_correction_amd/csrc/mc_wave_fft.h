@@ -270,3 +270,40 @@ MC_HD void wf_dft8(wf2 (&a)[8]) {  // full forward 8-point DFT, natural order in
 //   exchange 2: entry (k2, n3, k1) at ((n3 * 8 + (k2 ^ n3)) * 8) + k1
 MC_HD int wf5_x1(int k1, int n2, int n3) { return ((n2 * 8 + (k1 ^ n2)) * 8) + (n3 ^ (4 * (k1 >> 2))); }
 MC_HD int wf5_x2(int k2, int n3, int k1) { return ((n3 * 8 + (k2 ^ n3)) * 8) + k1; }
+
+// =====================================================================================
+// 1024-point variant for the COLUMNS of 1024 x 1024 patches (complex in, complex out).
+// N = 16 x 8 x 8, sixteen values per lane:  n = 64 n1 + 8 n2 + n3,  k = k1 + 16 k2 + 128 k3
+//   pass A  radix 16 over n1, twiddle W_1024^{q k1}   lane t owns q = 8 n2 + n3 = t
+//   pass B  radix  8 over n2, twiddle W_64^{n3 k2}    lane t owns (k1, n3) = (t & 15, (t >> 4) + 4 b), b = 0, 1
+//   pass C  radix  8 over n3                           lane t owns (k1, k2) = (t & 15, (t >> 4) + 4 b)
+// Two whole-line exchanges through a 1024-entry (8 KiB) wave-private slab:
+//   exchange 1: entry (k1, q)       at k1 * 64 + (q ^ ((2 * k1) & 31))
+//   exchange 2: entry (k1, k2, n3)  at n3 * 128 + k2 * 16 + k1
+// (conflict-free for 8-byte writes in 16-lane groups and 8-byte reads in 32-lane groups).
+// =====================================================================================
+#define WF10_N 1024
+MC_HD int wf10_x1(int k1, int q) { return k1 * 64 + (q ^ ((2 * k1) & 31)); }
+MC_HD int wf10_x2(int k1, int k2, int n3) { return n3 * 128 + k2 * 16 + k1; }
+
+// w^1 .. w^7 from w^1 (depth <= 3 products), applied to a[1..7]
+MC_HD void wf_twiddle8(wf2 (&a)[8], wf2 w1) {
+  const wf2 w2 = wf_cmul(w1, w1), w3 = wf_cmul(w2, w1), w4 = wf_cmul(w2, w2);
+  a[1] = wf_cmul(a[1], w1);
+  a[2] = wf_cmul(a[2], w2);
+  a[3] = wf_cmul(a[3], w3);
+  a[4] = wf_cmul(a[4], w4);
+  a[5] = wf_cmul(a[5], wf_cmul(w4, w1));
+  a[6] = wf_cmul(a[6], wf_cmul(w4, w2));
+  a[7] = wf_cmul(a[7], wf_cmul(w4, w3));
+}
+// w^1 .. w^15 from the exact w^1, w^2, w^4, w^8, applied to a[1..15]
+MC_HD void wf_twiddle16(wf2 (&a)[16], wf2 w1, wf2 w2, wf2 w4, wf2 w8) {
+  const wf2 w3 = wf_cmul(w2, w1), w5 = wf_cmul(w4, w1), w6 = wf_cmul(w4, w2), w7 = wf_cmul(w4, w3);
+  a[1] = wf_cmul(a[1], w1); a[2] = wf_cmul(a[2], w2); a[3] = wf_cmul(a[3], w3); a[4] = wf_cmul(a[4], w4);
+  a[5] = wf_cmul(a[5], w5); a[6] = wf_cmul(a[6], w6); a[7] = wf_cmul(a[7], w7); a[8] = wf_cmul(a[8], w8);
+  a[9] = wf_cmul(a[9], wf_cmul(w8, w1)); a[10] = wf_cmul(a[10], wf_cmul(w8, w2));
+  a[11] = wf_cmul(a[11], wf_cmul(w8, w3)); a[12] = wf_cmul(a[12], wf_cmul(w8, w4));
+  a[13] = wf_cmul(a[13], wf_cmul(w8, w5)); a[14] = wf_cmul(a[14], wf_cmul(w8, w6));
+  a[15] = wf_cmul(a[15], wf_cmul(w8, w7));
+}

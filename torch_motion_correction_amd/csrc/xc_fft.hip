@@ -763,6 +763,135 @@ __global__ __launch_bounds__(MC_WG) void xc_cols_fwd(const cfloat* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------ K2 / K3, wave per 1024-point column
+// Columns of 1024 x 1024 patches (H = 1024, at most 128 kept rows at either end of the
+// spectrum): one wavefront per column, four columns per workgroup, the 16 x 8 x 8 transform of
+// mc_wave_fft.h (third part) in registers, no workgroup barrier.  The workgroup-per-column
+// kernels spend a 1024-point column on 256 threads (4 values each) and 7 barriers.
+// K2: only the kept output rows are produced (k3 in {0, 7} of the last radix-8 pass).
+// K3: only the kept input rows are fetched (n1 in {0, 1, 14, 15} of the first radix-16 pass);
+//     the inverse runs the forward kernel on conjugated data.
+__device__ __forceinline__ void wf10_passes_ab(wf2 (&a)[16], int t, wf2* slab, const cfloat* __restrict__ tw,
+                                               wf2 (&B)[2][8]) {
+  wf_twiddle16(a, wf_from(tw[t]), wf_from(tw[2 * t]), wf_from(tw[4 * t]), wf_from(tw[8 * t]));
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) slab[wf10_x1(k1, t)] = a[k1];
+  wf_sync();
+  const int k1 = t & 15;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int n3 = (t >> 4) + 4 * b;
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2) B[b][n2] = slab[wf10_x1(k1, 8 * n2 + n3)];
+  }
+  wf_sync();
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    wf_dft8(B[b]);
+    wf_twiddle8(B[b], wf_from(tw[16 * ((t >> 4) + 4 * b)]));  // W_64^{n3 k2}
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) slab[wf10_x2(k1, k2, (t >> 4) + 4 * b)] = B[b][k2];
+  }
+  wf_sync();
+}
+
+__global__ __launch_bounds__(256) void xc_cols_fwd_wave1024(const cfloat* __restrict__ T1,
+                                                            const float* __restrict__ filt,
+                                                            cfloat* __restrict__ S,
+                                                            const cfloat* __restrict__ tw_col, XcGeom g,
+                                                            const float* __restrict__ fix,
+                                                            const cfloat* __restrict__ Mhat) {
+  constexpr int H = 1024;
+  __shared__ __attribute__((aligned(16))) wf2 slabs[4][WF10_N];
+  const int t = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int kx = blockIdx.x * 4 + wv, job = blockIdx.y;
+  if (kx >= g.nkx) return;  // no workgroup barrier below
+  wf2* slab = slabs[wv];
+  const int nky = g.kyp + g.kyn;
+  const cfloat* col = T1 + ((int64_t)job * g.nkx + kx) * g.ny;
+  cfloat* out = S + ((int64_t)job * g.nkx + kx) * nky;
+  const float* f = filt ? filt + (int64_t)kx * nky : nullptr;
+  const cfloat* mh = fix ? Mhat + (int64_t)kx * nky : nullptr;
+  const float dmean = fix ? fix[0] : 0.f, rstd = fix ? fix[1] : 1.f;
+  wf2 a[16], B[2][8];
+#pragma unroll
+  for (int n1 = 0; n1 < 16; ++n1) {
+    const int yy = 64 * n1 + t - g.y0;
+    a[n1] = (yy >= 0 && yy < g.ny) ? wf_from(col[yy]) : wf2{0.f, 0.f};
+  }
+  wf_dft16(a);
+  wf10_passes_ab(a, t, slab, tw_col, B);
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int k1 = t & 15, k2 = (t >> 4) + 4 * b;
+    wf2 e[4], o[4], z[8];
+#pragma unroll
+    for (int n3 = 0; n3 < 8; ++n3) {
+      const wf2 v = slab[wf10_x2(k1, k2, n3)];
+      if (n3 & 1) o[n3 >> 1] = v; else e[n3 >> 1] = v;
+    }
+    wf_dft8_pruned<1>(e, o, z);  // k3 = 0 and 7
+    const int c = k1 + 16 * k2;  // ky = c (k3 = 0) and c + 896 (k3 = 7)
+#pragma unroll
+    for (int sel = 0; sel < 2; ++sel) {
+      const int ky = sel ? c + 896 : c;
+      int kyi = -1;
+      if (ky < g.kyp) kyi = ky;
+      else if (ky >= H - g.kyn) kyi = ky - (H - g.kyn) + g.kyp;
+      if (kyi >= 0) {
+        cfloat v = wf_to(z[sel ? 7 : 0]);
+        if (fix) {
+          const cfloat m = mh[kyi];
+          v = cmake((v.x - dmean * m.x) * rstd, (v.y - dmean * m.y) * rstd);
+        }
+        out[kyi] = f ? cscale(v, f[kyi]) : v;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void xc_cols_inv_wave1024(
+    const cfloat* __restrict__ S_cur, const int* __restrict__ cur_idx,
+    const cfloat* __restrict__ S_ref, const int* __restrict__ ref_idx, cfloat* __restrict__ T2,
+    const cfloat* __restrict__ tw_col, float scale, XcGeom g) {
+  constexpr int H = 1024;
+  __shared__ __attribute__((aligned(16))) wf2 slabs[4][WF10_N];
+  const int t = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int kx = blockIdx.x * 4 + wv, p = blockIdx.y;
+  if (kx >= g.nkx) return;  // no workgroup barrier below
+  wf2* slab = slabs[wv];
+  const int nky = g.kyp + g.kyn;
+  const cfloat* cur = S_cur + ((int64_t)cur_idx[p] * g.nkx + kx) * nky;
+  const cfloat* ref = S_ref + ((int64_t)ref_idx[p] * g.nkx + kx) * nky;
+  cfloat* out = T2 + ((int64_t)p * g.nkx + kx) * H;
+  wf2 a[16], B[2][8];
+#pragma unroll
+  for (int n1 = 0; n1 < 16; ++n1) {
+    a[n1] = wf2{0.f, 0.f};
+    if (n1 < 2 || n1 >= 14) {  // the only input rows a band-limited spectrum can hold
+      const int kyi = kept_index(64 * n1 + t, H, g.kyp, g.kyn);
+      if (kyi >= 0) {
+        const cfloat v = cscale(cmulc(ref[kyi], cur[kyi]), scale);
+        a[n1] = wf2{v.x, -v.y};  // conjugate in, conjugate out: inverse transform
+      }
+    }
+  }
+  wf_dft16(a);
+  wf10_passes_ab(a, t, slab, tw_col, B);
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int k1 = t & 15, k2 = (t >> 4) + 4 * b;
+    wf2 c[8];
+#pragma unroll
+    for (int n3 = 0; n3 < 8; ++n3) c[n3] = slab[wf10_x2(k1, k2, n3)];
+    wf_dft8(c);
+#pragma unroll
+    for (int k3 = 0; k3 < 8; ++k3) out[k1 + 16 * k2 + 128 * k3] = cmake(c[k3].x, -c[k3].y);
+  }
+}
+
 // ------------------------------------------------------------------ K3: columns inverse
 // pair p: cur spectrum index cur_idx[p] in S_cur, ref spectrum index ref_idx[p] in S_ref.
 // MODE 0: conj(ref)*cur (cross-correlation); MODE 1: cur * phase ramp (Fourier shift,
@@ -1358,6 +1487,12 @@ int mc_xc_cols_forward_fix(const void* T1, const float* filt, void* S, const voi
   if (rc) return rc;
   if (!T1 || !S || !tw_col || njobs < 1 || (fix && !Mhat)) return MC_ERR_ARG;
   dim3 grid(g.nkx, njobs);
+  if (g.H == 1024 && g.kyp <= 128 && g.kyn <= 128 && g_col_engine == 0) {
+    hipLaunchKernelGGL(xc_cols_fwd_wave1024, dim3((g.nkx + 3) / 4, njobs), dim3(256), 0, (hipStream_t)stream,
+                       (const cfloat*)T1, filt, (cfloat*)S, (const cfloat*)tw_col, g, fix,
+                       (const cfloat*)Mhat);
+    return mc_check_launch();
+  }
   if (g.H == 4096 && g.kyp <= 512 && g.kyn <= 512 && g_col_engine == 0) {
     hipLaunchKernelGGL((xc_cols_fwd<12, true>), dim3((g.nkx + XC_FWD_COLS - 1) / XC_FWD_COLS, njobs),
                        dim3(MC_WG), 0, (hipStream_t)stream,
@@ -1380,6 +1515,12 @@ int mc_xc_cols_inverse(const void* S_cur, const int* cur_idx, const void* S_ref,
   int rc = geom_from(q, &g, false, true);
   if (rc) return rc;
   if (!S_cur || !cur_idx || !S_ref || !ref_idx || !T2 || !tw_col || npairs < 1) return MC_ERR_ARG;
+  if (g.H == 1024 && g.kyp <= 128 && g.kyn <= 128 && g_col_engine == 0) {
+    hipLaunchKernelGGL(xc_cols_inv_wave1024, dim3((g.nkx + 3) / 4, npairs), dim3(256), 0, (hipStream_t)stream,
+                       (const cfloat*)S_cur, cur_idx, (const cfloat*)S_ref, ref_idx, (cfloat*)T2,
+                       (const cfloat*)tw_col, scale, g);
+    return mc_check_launch();
+  }
   dim3 grid(g.nkx, npairs);
   MC_DISPATCH_LOG(mc_ilog2(g.H), {
     hipLaunchKernelGGL((xc_cols_inv<L, 0>), grid, dim3(MC_WG), 0, (hipStream_t)stream,
