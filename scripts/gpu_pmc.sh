@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d gpurun_out/$tag -- python3 $prog > gpurun_out/$tag.log 2>&1
 rc=$?
 grep -v rocprofv3 gpurun_out/$tag.log | tail -8
-f=$(find gpurun_out/$tag -name "*counter_collection.csv" | head -1)
+f=$(ls -t $(find gpurun_out/$tag -name "*counter_collection.csv") | head -1)
 python3 - "$f" "$pat" <<'PY'
 import csv, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))

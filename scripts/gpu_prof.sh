@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary $BENCH_ARGS > gpurun_out/$tag.log 2>&1
 rc=$?
 tail -1 gpurun_out/$tag.log | cut -c1-400
-f=$(find gpurun_out/$tag -name "*kernel_stats.csv" | head -1)
+f=$(ls -t $(find gpurun_out/$tag -name "*kernel_stats.csv") | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))

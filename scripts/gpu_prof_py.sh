@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag -- python3 "$@" > gpurun_out/$tag.log 2>&1
 rc=$?
 grep -v rocprofv3 gpurun_out/$tag.log | tail -6
-f=$(find gpurun_out/$tag -name "*kernel_stats.csv" | head -1)
+f=$(ls -t $(find gpurun_out/$tag -name "*kernel_stats.csv") | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))

@@ -9,10 +9,10 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/${tag}_$c -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary --no-overlap > gpurun_out/${tag}_$c.log 2>&1 || exit 1
 done
 python3 - gpurun_out/${tag}_FETCH_SIZE gpurun_out/${tag}_WRITE_SIZE <<'PY'
-import csv, sys, glob, collections, json
+import csv, sys, glob, collections, json, os
 out = collections.defaultdict(lambda: {"n": 0, "FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "ns": 0.0})
 for d in sys.argv[1:]:
-    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    f = max(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)  # newest run
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"][:64]
         out[k][r["Counter_Name"]] += float(r["Counter_Value"])
