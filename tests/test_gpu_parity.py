@@ -780,3 +780,13 @@ def test_wave1024_patch_columns_match_workgroup_engine(dev):
     for a, b in zip(res[0], res[1]):
         assert torch.isfinite(a).all()
         assert float((a - b).abs().max()) <= 5e-6 * float(b.abs().max())
+
+
+def test_wide_band_on_4096_frames_takes_the_general_kernels(mc, dev):
+    """frequency_range (300, 4) keeps 1025 rfft columns and 2049 fft rows of a 4096^2 frame:
+    beyond what the wave-per-row K1 (nkx <= 512) and the radix-16 columns (<= 512 kept rows per
+    end) are built for, so the workgroup kernels run; the drift must still be recovered."""
+    st, dy, dx = drift_stack(3, 4096, 4096, seed=21)
+    f = mc.estimate_global_motion(st.to(dev), 1.0, frequency_range=(300, 4)).cpu()
+    assert f[0, :, 0, 0].tolist() == [float(d - dy[1]) for d in dy]
+    assert f[1, :, 0, 0].tolist() == [float(d - dx[1]) for d in dx]
