@@ -12,6 +12,11 @@ Pinning status (see DESIGN.md section "Oracle"):
     PINNED against the reference's own ``patch_grid`` sub-package (importable in
     the build container; goldens in tests/golden/patch_grid_*.npz were produced by
     the reference code itself, see oracle/make_goldens.py).
+  * normalize_image, array_to_grid_sample, image_shifts_to_deformation_field, the
+    sub-pixel refinement, outlier rejection, temporal smoothing and get_pixel_shifts are
+    PINNED bit for bit against the reference's own functions (its modules import once the
+    absent packages are bound to stubs that raise when called; outputs on seeded inputs in
+    tests/golden/reference_helpers.npz, see oracle/make_goldens.py).
   * ``scipy.signal.savgol_filter`` is the real dependency (scipy is installed).
   * everything that the reference delegates to the five un-vendored teamtomo
     packages (torch_grid_utils, torch_fourier_filter, torch_fourier_shift,

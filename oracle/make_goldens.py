@@ -14,6 +14,12 @@ Two kinds of vectors are written:
   result from replaying the reference's per-frame loop (xc.py:297-346) on the
   reference's LazyPatchGrid with a scalar "mask" of 2.0 (log2 of the value read =
   number of times that memo entry had been multiplied in place).
+* ``reference_helpers.npz`` -- also produced by the REFERENCE's own code: utils.py,
+  estimate_motion_xc.py, correct_motion.py and deformation_field_utils.py are imported with
+  the five absent packages bound to stubs that raise when called, and the reference's
+  torch/scipy-only helpers are run on seeded inputs: normalize_image, array_to_grid_sample,
+  image_shifts_to_deformation_field, _apply_sub_pixel_refinement, _apply_outlier_rejection,
+  _apply_temporal_smoothing, get_pixel_shifts.  Nothing third-party is emulated.
 * ``oracle_*.npz`` -- outputs of the oracle itself (parity unpinned at the
   third-party boundaries) on the reference's test fixtures and on the SURVEY
   section 8d synthetic drift stack; used as regression pins and as the expected
@@ -100,6 +106,108 @@ def reference_vectors():
     print("wrote patch_grid_reference.npz", len(out), "arrays")
 
 
+THIRD_PARTY = {  # absent packages -> names the reference imports from them at module level
+    "torch_fourier_filter": [], "torch_fourier_filter.envelopes": ["b_envelope"],
+    "torch_fourier_filter.bandpass": ["bandpass_filter"],
+    "torch_grid_utils": ["circle", "coordinate_grid"],
+    "torch_cubic_spline_grids": ["CubicBSplineGrid3d", "CubicCatmullRomGrid3d"],
+    "torch_fourier_shift": ["fourier_shift_dft_2d"],
+    "torch_image_interpolation": ["sample_image_2d"],
+    "torch_image_interpolation.grid_sample_utils": ["array_to_grid_sample"],
+}
+
+
+def _reference_modules_behind_inert_stubs():
+    """Import the reference's OWN modules (utils, estimate_motion_xc, correct_motion,
+    deformation_field_utils).  Their top-level imports name five absent third-party packages;
+    those names are bound to stubs that RAISE when called, so nothing third-party is emulated:
+    only reference functions that use torch / scipy / einops alone can run (and only those are
+    captured below).  The one exception is documented at get_pixel_shifts."""
+    def refuse(name):
+        def f(*a, **k):
+            raise NotImplementedError(f"{name} is a third-party function that is absent here")
+        return f
+
+    for mod, names in THIRD_PARTY.items():
+        m = types.ModuleType(mod)
+        m.__path__ = []
+        for n in names:
+            if n[0].isupper():  # class names appear in type annotations: an inert class
+                setattr(m, n, type(n, (), {"__init__": refuse(f"{mod}.{n}"),
+                                           "from_grid_data": staticmethod(refuse(f"{mod}.{n}.from_grid_data"))}))
+            else:
+                setattr(m, n, refuse(f"{mod}.{n}"))
+        sys.modules[mod] = m
+    _reference_patch_grid()
+    mods = {n: importlib.import_module(f"torch_motion_correction.{n}")
+            for n in ("utils", "deformation_field_utils", "correct_motion", "estimate_motion_xc")}
+    return mods
+
+
+def reference_helper_vectors():
+    """tests/golden/reference_helpers.npz: outputs of the reference's own helper functions
+    (the code under /root/reference, imported, not restated) on seeded inputs."""
+    import contextlib
+    import io
+
+    m = _reference_modules_behind_inert_stubs()
+    xc, utils, dfu, cm = m["estimate_motion_xc"], m["utils"], m["deformation_field_utils"], m["correct_motion"]
+    g = torch.Generator().manual_seed(2024)
+    out = {}
+    with contextlib.redirect_stdout(io.StringIO()):
+        # a2 normalize_image (utils.py:49-84)
+        img = torch.randn(4, 40, 56, generator=g) * 3.0 + 7.0
+        out["norm_in"], out["norm_out"] = img.numpy(), utils.normalize_image(img).numpy()
+        # array_to_grid_sample (utils.py:9-30)
+        coords = torch.rand(5, 7, 2, generator=g) * torch.tensor([39.0, 55.0])
+        out["a2g_in"], out["a2g_out"] = coords.numpy(), utils.array_to_grid_sample(coords, (40, 56)).numpy()
+        # a7 image_shifts_to_deformation_field (deformation_field_utils.py:129-162)
+        sh = torch.randn(6, 2, generator=g)
+        out["s2f_in"] = sh.numpy()
+        out["s2f_out"] = dfu.image_shifts_to_deformation_field(sh, pixel_spacing=1.7).numpy()
+        # a11 _apply_sub_pixel_refinement (estimate_motion_xc.py:414-483): interior peaks, a
+        # border peak (Q4) and a flat axis (Q5)
+        ph, pw, n = 12, 16, 6
+        cc = torch.randn(n, ph * pw, generator=g)
+        peaks = torch.tensor([5 * pw + 7, 0 * pw + 3, 6 * pw + 15, 11 * pw + 8, 4 * pw + 4, 7 * pw + 9])
+        cc[torch.arange(n), peaks] += 6.0
+        cc[4].view(ph, pw)[3, 4] = cc[4].view(ph, pw)[5, 4]  # equal outer samples in y
+        py, px = xc._apply_sub_pixel_refinement(cc, peaks, ph, pw)
+        out["sp_cc"], out["sp_peaks"] = cc.numpy(), peaks.numpy()
+        out["sp_y"], out["sp_x"] = py.numpy(), px.numpy()
+        # a12 _apply_outlier_rejection (estimate_motion_xc.py:538-627): one outlier, none, all equal
+        cases = []
+        sy, sx = torch.randn(4, 5, generator=g) * 0.3, torch.randn(4, 5, generator=g) * 0.3
+        sy[1, 2] = 25.0
+        cases.append((sy, sx, 3.0))
+        cases.append((torch.randn(3, 3, generator=g), torch.randn(3, 3, generator=g), 3.0))
+        cases.append((torch.full((2, 3), 1.5), torch.full((2, 3), -0.5), 2.0))
+        a, b = torch.randn(2, 2, generator=g), torch.randn(2, 2, generator=g)
+        cases.append((a, b, 0.1))  # tiny threshold: everything is rejected -> median fallback
+        for i, (a, b, thr) in enumerate(cases):
+            ry, rx = xc._apply_outlier_rejection(a.clone(), b.clone(), thr, 0)
+            out[f"or{i}_y"], out[f"or{i}_x"], out[f"or{i}_thr"] = a.numpy(), b.numpy(), np.float32(thr)
+            out[f"or{i}_oy"], out[f"or{i}_ox"] = ry.numpy(), rx.numpy()
+        # a13 _apply_temporal_smoothing (estimate_motion_xc.py:486-535): odd, even and too-long windows
+        fld = torch.randn(2, 9, 2, 3, generator=g)
+        out["ts_in"] = fld.numpy()
+        for wdw in (5, 4, 3, 15, 2):
+            out[f"ts_out_{wdw}"] = xc._apply_temporal_smoothing(fld.clone(), wdw, torch.device("cpu")).numpy()
+        # a18 get_pixel_shifts (correct_motion.py:132-185).  It calls array_to_grid_sample under
+        # the name it imports from torch_image_interpolation; the reference keeps an identical
+        # copy of that function in its own utils.py:9-30, which is what is bound here.
+        cm.array_to_grid_sample = utils.array_to_grid_sample
+        frame = torch.zeros(37, 53)
+        lattice = torch.randn(2, 20, 30, generator=g) * 2.0
+        yy, xx = torch.meshgrid(torch.arange(37, dtype=torch.float32), torch.arange(53, dtype=torch.float32),
+                                indexing="ij")
+        pixel_grid = torch.stack([yy, xx], dim=-1)
+        out["gps_lattice"] = lattice.numpy()
+        out["gps_out"] = cm.get_pixel_shifts(frame, 1.3, lattice, pixel_grid).numpy()
+    np.savez_compressed(os.path.join(GOLD, "reference_helpers.npz"), **out)
+    print("wrote reference_helpers.npz", len(out), "arrays")
+
+
 def blob_stack(moving: bool):
     """tests/test_estimate_motion.py:13-33 and tests/test_correct_motion.py:15-32."""
     t, h, w = 5, 64, 64
@@ -165,6 +273,7 @@ if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     if os.path.isdir(REF_SRC):
         reference_vectors()
+        reference_helper_vectors()
     else:
         print("reference not present: patch_grid_reference.npz not regenerated")
     oracle_vectors()

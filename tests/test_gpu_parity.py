@@ -13,6 +13,8 @@ Tolerances (north star: 1e-4 relative on float32):
     section 6).  The excluded fraction is asserted to be small.
 """
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -790,3 +792,25 @@ def test_wide_band_on_4096_frames_takes_the_general_kernels(mc, dev):
     f = mc.estimate_global_motion(st.to(dev), 1.0, frequency_range=(300, 4)).cpu()
     assert f[0, :, 0, 0].tolist() == [float(d - dy[1]) for d in dy]
     assert f[1, :, 0, 0].tolist() == [float(d - dx[1]) for d in dx]
+
+
+# ------------------------------------------------------------------ against the reference's own helpers
+
+
+def test_product_matches_reference_helper_vectors(mc, dev):
+    """tests/golden/reference_helpers.npz holds outputs of the reference's OWN functions
+    (oracle/make_goldens.py::reference_helper_vectors): normalize_image (utils.py:49-84) and
+    get_pixel_shifts (correct_motion.py:132-185) are compared with the HIP path directly."""
+    from torch_motion_correction_amd import engine
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_helpers.npz")
+    ref = {k: torch.from_numpy(v) for k, v in np.load(path, allow_pickle=False).items() if v.ndim}
+    img = ref["norm_in"].to(dev)
+    got = engine.normalize(img, engine.central_box_stats(img)).cpu()
+    assert float((got - ref["norm_out"]).abs().max()) <= 2e-6 * float(ref["norm_out"].abs().max())
+    yy, xx = torch.meshgrid(torch.arange(37, dtype=torch.float32), torch.arange(53, dtype=torch.float32),
+                            indexing="ij")
+    shifts = mc.get_pixel_shifts(torch.zeros(37, 53, device=dev), 1.3, ref["gps_lattice"].to(dev),
+                                 torch.stack([yy, xx], dim=-1).to(dev)).cpu()
+    assert shifts.shape == ref["gps_out"].shape
+    assert float((shifts - ref["gps_out"]).abs().max()) <= 1e-5 * float(ref["gps_out"].abs().max())

@@ -1,6 +1,8 @@
 """CPU tests of the oracle: pinned against the reference-produced goldens, against the
 assertions of the reference's own test-suite, and against its own committed outputs."""
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -256,3 +258,62 @@ def test_dose_weighted_sum_properties():
     # linear in the movie
     assert torch.allclose(oracle.dose_weighted_sum(3 * m, 1.3, 2.0), 3 * oracle.dose_weighted_sum(m, 1.3, 2.0),
                           atol=1e-4)
+
+
+# ------------------------------------------------------------------ pinned by the reference's own helpers
+
+
+@pytest.fixture(scope="module")
+def refh():
+    """tests/golden/reference_helpers.npz: produced by the REFERENCE's own functions (imported
+    from /root/reference with the absent third-party packages bound to stubs that raise;
+    oracle/make_goldens.py::reference_helper_vectors)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_helpers.npz")
+    return {k: torch.from_numpy(v) if v.ndim else v for k, v in np.load(path, allow_pickle=False).items()}
+
+
+def test_oracle_normalize_and_field_helpers_match_the_reference(refh):
+    from oracle import motion
+
+    assert torch.equal(motion.normalize_image(refh["norm_in"]), refh["norm_out"])  # utils.py:49-84
+    assert torch.equal(tp.array_to_grid_sample(refh["a2g_in"], (40, 56)), refh["a2g_out"])  # utils.py:9-30
+    got = motion.image_shifts_to_deformation_field(refh["s2f_in"], 1.7)  # dfu.py:129-162
+    assert got.shape == refh["s2f_out"].shape and torch.equal(got, refh["s2f_out"])
+
+
+def test_oracle_sub_pixel_refinement_matches_the_reference(refh):
+    """estimate_motion_xc.py:414-483 incl. the border rule (Q4) and the equal-samples rule (Q5)."""
+    from oracle import motion
+
+    cc, peaks = refh["sp_cc"], refh["sp_peaks"]
+    py, px = motion._sub_pixel(cc.view(cc.shape[0], 12, 16), peaks, 12, 16)
+    assert torch.equal(py, refh["sp_y"]) and torch.equal(px, refh["sp_x"])
+    assert float(py[1]) == 0.0 and float(px[2]) == 15.0  # border peaks stay integer
+
+
+def test_oracle_outlier_rejection_matches_the_reference(refh):
+    """estimate_motion_xc.py:538-627: one outlier, none, a constant field, everything rejected."""
+    from oracle import motion
+
+    for i in range(4):
+        oy, ox = motion._reject_outliers(refh[f"or{i}_y"], refh[f"or{i}_x"], float(refh[f"or{i}_thr"]))
+        assert torch.equal(oy, refh[f"or{i}_oy"]) and torch.equal(ox, refh[f"or{i}_ox"]), i
+    assert not torch.equal(refh["or0_oy"], refh["or0_y"])  # the planted outlier was replaced
+
+
+def test_oracle_temporal_smoothing_matches_the_reference(refh):
+    """estimate_motion_xc.py:486-535: odd, even (-> next odd), minimal, too long (-> t) and no-op windows."""
+    from oracle import motion
+
+    for wdw in (5, 4, 3, 15, 2):
+        assert torch.equal(motion._smooth_time(refh["ts_in"].clone(), wdw), refh[f"ts_out_{wdw}"]), wdw
+
+
+def test_oracle_pixel_shifts_match_the_reference(refh):
+    """correct_motion.py:132-185 (bicubic / reflection / align_corners upsample of the lattice)."""
+    from oracle import motion
+
+    yy, xx = torch.meshgrid(torch.arange(37, dtype=torch.float32), torch.arange(53, dtype=torch.float32),
+                            indexing="ij")
+    got = motion.get_pixel_shifts(torch.zeros(37, 53), 1.3, refh["gps_lattice"], torch.stack([yy, xx], dim=-1))
+    assert torch.equal(got, refh["gps_out"])
