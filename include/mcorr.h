@@ -136,19 +136,22 @@ int mc_xc_cols_inverse(const void* S_cur, const int* cur_idx, const void* S_ref,
 
 /* K3+K4+K5 for the arg-max search without materialising the map or T2 (power-of-two
  * W and H >= 256; estimate_motion_xc.py:106-123).  Rows [0, n) and [H-n, H) of the
- * correlation map (n = mc_xc_near_rows(geom), |shift_y| < n) are transformed from T2_near
+ * correlation map (n = mc_xc_near_rows(geom)) are transformed from T2_near
  * ([p][kx][2n] complex) while the column pass accumulates the per-row triangle-inequality
  * bounds of ALL rows; only if a far row's bound can still reach the near-window maximum are
  * the full column pass (T2_full, [p][kx][H]) and the far row groups evaluated, a decision
  * taken on the device (the fallback kernels are enqueued and return at once).  The result
- * is the exact arg-max of the full map either way.  part_val: npairs*(H/RG) + npairs*H
- * floats; part_idx: npairs*(H/RG) + npairs + 1 ints. */
+ * is the exact arg-max of the full map either way.  n counts the searched rows plus a few
+ * guard rows, so that nb (optional, [p][3][3] floats: the map around every peak as
+ * mc_xc_peak_neighbourhood gives it, for the sub-pixel parabola fit of
+ * estimate_motion_xc.py:414-483) can be taken from T2_near too.  part_val: npairs*(H/RG) +
+ * npairs*H floats; part_idx: npairs*(H/RG) + npairs + 1 ints. */
 int mc_xc_near_rows(const mc_xc_geom* geom);
 int mc_xc_correlate_argmax(const void* S_cur, const int* cur_idx, const void* S_ref,
                            const int* ref_idx, void* T2_full, void* T2_near, float* part_val,
-                           int* part_idx, int* peaks, float* shifts, const void* tw_col,
-                           const void* tw_row, float scale, int npairs, const mc_xc_geom* geom,
-                           void* stream);
+                           int* part_idx, int* peaks, float* shifts, float* nb,
+                           const void* tw_col, const void* tw_row, float scale, int npairs,
+                           const mc_xc_geom* geom, void* stream);
 
 /* K4+K5.  Inverse real row FFT of T2 fused with the arg-max (first maximum, as
  * torch.argmax): peaks[p] = flat index y*W+x, shifts[p] = (sy,sx) after the

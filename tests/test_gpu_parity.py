@@ -814,3 +814,28 @@ def test_product_matches_reference_helper_vectors(mc, dev):
                                  torch.stack([yy, xx], dim=-1).to(dev)).cpu()
     assert shifts.shape == ref["gps_out"].shape
     assert float((shifts - ref["gps_out"]).abs().max()) <= 1e-5 * float(ref["gps_out"].abs().max())
+
+
+@pytest.mark.parametrize("strategy", ["mean_except_current", "middle_frame"])
+def test_patches_1024_near_window_search_with_sub_pixel(mc, dev, strategy):
+    """p = 1024 patches go through the wave kernels (rows 512-point dual, columns 1024-point)
+    and the near-window search incl. the 3x3 neighbourhood read from the compact buffer; the
+    result must equal the full-map path and the oracle."""
+    from torch_motion_correction_amd import engine
+
+    st, dy, dx = drift_stack(5, 1100, 1600, seed=17)  # 1 x 2 patches
+    got = {}
+    try:
+        for fused in (False, True):
+            engine.FUSED_SEARCH = fused
+            f, pos = mc.estimate_motion_cross_correlation_patches(st.to(dev), 1.0, patch_sidelength=1024,
+                                                                  reference_strategy=strategy)
+            got[fused] = (f.cpu(), pos.cpu())
+    finally:
+        engine.FUSED_SEARCH = True
+    assert torch.equal(got[True][1], got[False][1])
+    assert float((got[True][0] - got[False][0]).abs().max()) <= 1e-4
+    of, opos = oracle.estimate_motion_cross_correlation_patches(st, 1.0, patch_sidelength=1024,
+                                                                reference_strategy=strategy)
+    assert torch.equal(got[True][1], opos)
+    assert float((got[True][0] - of).abs().max()) <= 1e-4

@@ -943,17 +943,19 @@ __global__ __launch_bounds__(MC_WG) void xc_cols_inv(
 
 // K3 for the arg-max search without the full T2: a workgroup runs XC_NEAR_COLS columns of
 // one pair through the inverse column FFT, keeps only the rows of the near window
-// (|shift_y| < nnear: rows [0, nnear) and [H - nnear, H)) in T2n[p][kx][2 nnear] and adds
+// (rows [0, nstore) and [H - nstore, H), nstore = near rows + guard rows for the sub-pixel
+// neighbourhood of a peak on the window's edge) in T2n[p][kx][2 nstore] and adds
 // its share of the triangle-inequality row bounds (see K4) to bounds[p][y] -- per thread in
 // registers over its columns, then one float atomic per (thread, row).  The full map is
 // only ever materialised (xc_cols_inv, gated by `need_full`) when some far row's bound
 // reaches the maximum found in the near window.
 #define XC_NEAR_COLS 8
+#define XC_NEAR_GUARD 8  // extra stored rows per end: neighbourhood of a peak on the window's edge
 template <int LOGH, bool R16 = false>
 __global__ __launch_bounds__(MC_WG) void xc_cols_inv_near(
     const cfloat* __restrict__ S_cur, const int* __restrict__ cur_idx,
     const cfloat* __restrict__ S_ref, const int* __restrict__ ref_idx, cfloat* __restrict__ T2n,
-    float* __restrict__ bounds, const cfloat* __restrict__ tw_col, float scale, XcGeom g, int nnear) {
+    float* __restrict__ bounds, const cfloat* __restrict__ tw_col, float scale, XcGeom g, int nstore) {
   constexpr int H = 1 << LOGH;
   __shared__ __attribute__((aligned(16))) cfloat line[R16 ? H : lds_len(H)];
   constexpr int NOUT = H / MC_WG;  // rows per thread in the last pass (H >= 1024: all threads busy)
@@ -971,7 +973,7 @@ __global__ __launch_bounds__(MC_WG) void xc_cols_inv_near(
     if (kx >= g.nkx) break;  // workgroup-uniform
     const cfloat* cur = S_cur + ((int64_t)cur_idx[p] * g.nkx + kx) * nky;
     const cfloat* ref = S_ref + ((int64_t)ref_idx[p] * g.nkx + kx) * nky;
-    cfloat* outn = T2n + ((int64_t)p * g.nkx + kx) * (2 * nnear);
+    cfloat* outn = T2n + ((int64_t)p * g.nkx + kx) * (2 * nstore);
     const float wgt = kx == 0 ? 1.f : 2.f;
     auto load = [&](int ky) {
       const int kyi = kept_index(ky, H, g.kyp, g.kyn);
@@ -981,8 +983,8 @@ __global__ __launch_bounds__(MC_WG) void xc_cols_inv_near(
     auto load16 = [&](int, int ky) { return load(ky); };
     int c = 0;
     auto store = [&](int y, cfloat v) {
-      const int yn = y < nnear ? y : y - (H - 2 * nnear);  // position in the near window
-      if (yn >= 0 && yn < 2 * nnear && (y < nnear || y >= H - nnear)) outn[yn] = v;
+      const int yn = y < nstore ? y : y - (H - 2 * nstore);  // position in the stored window
+      if (yn >= 0 && yn < 2 * nstore && (y < nstore || y >= H - nstore)) outn[yn] = v;
       // hardware square root (1 ulp): the bound test carries a 1e-4 relative slack
       acc[c++] += wgt * __builtin_amdgcn_sqrtf(v.x * v.x + v.y * v.y);
     };
@@ -1139,9 +1141,13 @@ __global__ __launch_bounds__(MC_WG) void xc_rows_inv(const cfloat* __restrict__ 
       }
     }
   }
-  // compact: T2 holds only the near window, [p][kx][2 near RG] (xc_cols_inv_near)
-  const int cstride = compact ? 2 * near * RG : g.H;
-  const cfloat* in = T2 + (int64_t)p * g.nkx * cstride + (int64_t)(compact ? (int)blockIdx.x : grp) * RG;
+  // compact > 0: T2 holds only the stored window, [p][kx][2 nstore], nstore = near RG + guard,
+  // guard = compact - 1 rows (xc_cols_inv_near); the negative-shift groups start at nstore + guard
+  const int nstore = near * RG + (compact > 0 ? compact - 1 : 0);
+  const int cstride = compact ? 2 * nstore : g.H;
+  const int coff = (int)blockIdx.x < near ? (int)blockIdx.x * RG
+                                          : nstore + (compact - 1) + ((int)blockIdx.x - near) * RG;
+  const cfloat* in = T2 + (int64_t)p * g.nkx * cstride + (int64_t)(compact ? coff : grp * RG);
   for (int i = tid; i < g.nkx * RG; i += MC_WG) {
     const int kx = i / RG, r = i - kx * RG;
     stg[kx * (RG + 1) + r] = in[(int64_t)kx * cstride + r];
@@ -1248,11 +1254,15 @@ __global__ void xc_peak_final(const float* __restrict__ part_val, const int* __r
 // nb[p][dy][dx] (3x3 floats) = correlation values around peaks[p], produced by the
 // same inverse-row arithmetic as K4 so the values are the ones the arg-max saw.
 // Entries outside the map are NaN.
+// T2n / gate / nstore (optional): while gate[0] == 0 the map rows live in the compact
+// near-window buffer T2n[p][kx][2 nstore] of xc_cols_inv_near, otherwise in the full T2.
 template <int LOGN>
 __global__ __launch_bounds__(MC_WG) void xc_peak_nbhd(const cfloat* __restrict__ T2,
                                                       const int* __restrict__ peaks,
                                                       float* __restrict__ nb,
-                                                      const cfloat* __restrict__ tw_row, XcGeom g) {
+                                                      const cfloat* __restrict__ tw_row, XcGeom g,
+                                                      const cfloat* __restrict__ T2n,
+                                                      const int* __restrict__ gate, int nstore) {
   constexpr int N = 1 << LOGN;
   __shared__ __attribute__((aligned(16))) cfloat line[lds_len(N)];
   const int tid = threadIdx.x;
@@ -1266,7 +1276,17 @@ __global__ __launch_bounds__(MC_WG) void xc_peak_nbhd(const cfloat* __restrict__
     return;
   }
   const cfloat* in = T2 + (int64_t)p * g.nkx * g.H + y;
-  auto X = [&](int k) { return in[(int64_t)k * g.H]; };
+  int64_t cs = g.H;
+  if (T2n && gate[0] == 0) {  // workgroup-uniform
+    const int yn = y < nstore ? y : y - (g.H - 2 * nstore);
+    if (yn < 0 || yn >= 2 * nstore || (y >= nstore && y < g.H - nstore)) {  // not stored (cannot
+      if (tid < 3) o[tid] = __builtin_nanf("");  // happen for a peak inside the near window)
+      return;
+    }
+    cs = 2 * nstore;
+    in = T2n + (int64_t)p * g.nkx * cs + yn;
+  }
+  auto X = [&](int k) { return in[(int64_t)k * cs]; };
   auto load = [&](int k) {
     const int km = N - k;
     cfloat xk = (k < g.nkx) ? X(k) : cmake(0.f, 0.f);
@@ -1603,12 +1623,12 @@ int mc_xc_near_rows(const mc_xc_geom* q) {
   if (rc) return rc;
   int near = (64 + g.RG - 1) / g.RG;
   if (2 * near > g.H / g.RG) near = (g.H / g.RG) / 2;
-  return near * g.RG;
+  return near * g.RG + XC_NEAR_GUARD;  // searched rows + guard rows, per end of the map
 }
 
 int mc_xc_correlate_argmax(const void* S_cur, const int* cur_idx, const void* S_ref,
                            const int* ref_idx, void* T2_full, void* T2_near, float* part_val,
-                           int* part_idx, int* peaks, float* shifts, const void* tw_col,
+                           int* part_idx, int* peaks, float* shifts, float* nb, const void* tw_col,
                            const void* tw_row, float scale, int npairs, const mc_xc_geom* q,
                            void* stream) {
   XcGeom g;
@@ -1626,7 +1646,7 @@ int mc_xc_correlate_argmax(const void* S_cur, const int* cur_idx, const void* S_
   int near = (64 + g.RG - 1) / g.RG;
   if (2 * near > ngrp) near = ngrp / 2;
   if (near < 1) return MC_ERR_UNSUPPORTED;
-  const int nnear = near * g.RG;
+  const int nstore = near * g.RG + XC_NEAR_GUARD;
   int* best = part_idx + (int64_t)npairs * ngrp;  // npairs running maxima, then the gate word
   int* gate = best + npairs;
   float* bounds = part_val + (int64_t)npairs * ngrp;  // npairs * H row bounds
@@ -1635,13 +1655,13 @@ int mc_xc_correlate_argmax(const void* S_cur, const int* cur_idx, const void* S_
   if (g.H == 4096 && g.kyp <= 512 && g.kyn <= 512 && g_col_engine == 0) {
     hipLaunchKernelGGL((xc_cols_inv_near<12, true>), dim3((g.nkx + XC_NEAR_COLS - 1) / XC_NEAR_COLS, npairs),
                        dim3(MC_WG), 0, st, (const cfloat*)S_cur, cur_idx, (const cfloat*)S_ref, ref_idx,
-                       (cfloat*)T2_near, bounds, (const cfloat*)tw_col, scale, g, nnear);
+                       (cfloat*)T2_near, bounds, (const cfloat*)tw_col, scale, g, nstore);
   } else
   MC_DISPATCH_LOG(mc_ilog2(g.H), {
     if constexpr (L >= 10) {
       hipLaunchKernelGGL(xc_cols_inv_near<L>, dim3((g.nkx + XC_NEAR_COLS - 1) / XC_NEAR_COLS, npairs),
                          dim3(MC_WG), 0, st, (const cfloat*)S_cur, cur_idx, (const cfloat*)S_ref, ref_idx,
-                         (cfloat*)T2_near, bounds, (const cfloat*)tw_col, scale, g, nnear);
+                         (cfloat*)T2_near, bounds, (const cfloat*)tw_col, scale, g, nstore);
     } else {
       return MC_ERR_UNSUPPORTED;
     }
@@ -1655,8 +1675,8 @@ int mc_xc_correlate_argmax(const void* S_cur, const int* cur_idx, const void* S_
       (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3(2 * near, npairs), dim3(MC_WG), lds, st, (const cfloat*)T2_near,
                        (const float*)bounds, best, part_val, part_idx, (float*)nullptr,
-                       (const int64_t*)nullptr, (int64_t)0, (const cfloat*)tw_row, g, near, 0, 1,
-                       (const int*)nullptr);
+                       (const int64_t*)nullptr, (int64_t)0, (const cfloat*)tw_row, g, near, 0,
+                       1 + XC_NEAR_GUARD, (const int*)nullptr);
   });
   rc = mc_check_launch();
   if (rc) return rc;
@@ -1682,6 +1702,13 @@ int mc_xc_correlate_argmax(const void* S_cur, const int* cur_idx, const void* S_
   }
   hipLaunchKernelGGL(xc_peak_final, dim3(npairs), dim3(64), 0, st, part_val, part_idx, ngrp, g.H, g.W,
                      peaks, shifts);
+  if (nb) {  // 3 x 3 values around every peak (sub-pixel refinement), from whichever buffer holds the rows
+    MC_DISPATCH_LOG(logn, {
+      hipLaunchKernelGGL(xc_peak_nbhd<L>, dim3(3, npairs), dim3(MC_WG), 0, st, (const cfloat*)T2_full,
+                         (const int*)peaks, nb, (const cfloat*)tw_row, g, (const cfloat*)T2_near,
+                         (const int*)gate, nstore);
+    });
+  }
   return mc_check_launch();
 }
 
@@ -1717,7 +1744,8 @@ int mc_xc_peak_neighbourhood(const void* T2, const int* peaks, float* nb, const 
   dim3 grid(3, npairs);
   MC_DISPATCH_LOG(logn, {
     hipLaunchKernelGGL(xc_peak_nbhd<L>, grid, dim3(MC_WG), 0, (hipStream_t)stream,
-                       (const cfloat*)T2, peaks, nb, (const cfloat*)tw_row, g);
+                       (const cfloat*)T2, peaks, nb, (const cfloat*)tw_row, g, (const cfloat*)nullptr,
+                       (const int*)nullptr, 0);
   });
   return mc_check_launch();
 }

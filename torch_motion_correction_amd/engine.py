@@ -15,6 +15,7 @@ from . import _lib, lattice, plan as planmod, spline
 from ._lib import check, ptr, stream_ptr
 
 WORKSPACE_BYTES = 2 << 30  # soft cap for one transposed intermediate (T1 / T2)
+FUSED_SEARCH = True  # near-window arg-max (mc_xc_correlate_argmax); False: full T2 + separate kernels
 
 
 _CONST: dict = {}
@@ -146,9 +147,9 @@ def _peaks(S_cur, cur_idx, S_ref, ref_idx, pl, want_nbhd):
     pi = torch.empty(chunk * ngrp + chunk + 1, dtype=torch.int32, device=dev)
     st = stream_ptr(dev)
     scale = 1.0 / (g.H * g.W)
-    # arg-max only: near-window search, the full map (T2) is a device-side fallback that
-    # normally never runs (mc_xc_correlate_argmax)
-    fused = (not want_nbhd) and _pow2(g.W) and _pow2(g.H) and g.H >= 1024
+    # near-window search (+ the 3x3 neighbourhood of the peak when asked): the full map (T2) is
+    # a device-side fallback that normally never runs (mc_xc_correlate_argmax)
+    fused = FUSED_SEARCH and _pow2(g.W) and _pow2(g.H) and g.H >= 1024
     if fused:
         T2n = torch.empty((chunk, g.nkx, 2 * lib.mc_xc_near_rows(g), 2), dtype=torch.float32, device=dev)
     for a in range(0, npairs, chunk):
@@ -156,7 +157,8 @@ def _peaks(S_cur, cur_idx, S_ref, ref_idx, pl, want_nbhd):
         if fused:
             check(lib.mc_xc_correlate_argmax(ptr(S_cur), ptr(cur_idx[a : a + n]), ptr(S_ref),
                                              ptr(ref_idx[a : a + n]), ptr(T2), ptr(T2n), ptr(pv), ptr(pi),
-                                             ptr(peaks[a : a + n]), ptr(shifts[a : a + n]), ptr(pl.tw_col),
+                                             ptr(peaks[a : a + n]), ptr(shifts[a : a + n]),
+                                             ptr(nb[a : a + n]) if want_nbhd else None, ptr(pl.tw_col),
                                              ptr(pl.tw_row), scale, n, g, st), "mc_xc_correlate_argmax")
             continue
         if _pow2(g.H):
