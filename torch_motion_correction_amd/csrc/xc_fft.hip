@@ -892,6 +892,74 @@ __global__ __launch_bounds__(256) void xc_cols_inv_wave1024(
   }
 }
 
+// Near-window form of the same (see xc_cols_inv_near below): a wavefront runs XC_NEAR_COLS
+// columns of one pair, keeps the stored window's rows and its share of the row bounds (16 rows
+// per lane, in registers over the column loop).
+#define XC_NEAR_COLS_W 8
+__global__ __launch_bounds__(256) void xc_cols_inv_near_wave1024(
+    const cfloat* __restrict__ S_cur, const int* __restrict__ cur_idx,
+    const cfloat* __restrict__ S_ref, const int* __restrict__ ref_idx, cfloat* __restrict__ T2n,
+    float* __restrict__ bounds, const cfloat* __restrict__ tw_col, float scale, XcGeom g, int nstore) {
+  constexpr int H = 1024;
+  __shared__ __attribute__((aligned(16))) wf2 slabs[4][WF10_N];
+  const int t = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p = blockIdx.y;
+  const int kx0 = (blockIdx.x * 4 + wv) * XC_NEAR_COLS_W;
+  if (kx0 >= g.nkx) return;  // no workgroup barrier below
+  wf2* slab = slabs[wv];
+  const int nky = g.kyp + g.kyn;
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll 1
+  for (int cc = 0; cc < XC_NEAR_COLS_W; ++cc) {
+    const int kx = kx0 + cc;
+    if (kx >= g.nkx) break;  // wave-uniform
+    int tl = t;  // opaque per column: nothing derived from it is hoisted (registers)
+    asm volatile("" : "+v"(tl));
+    const cfloat* cur = S_cur + ((int64_t)cur_idx[p] * g.nkx + kx) * nky;
+    const cfloat* ref = S_ref + ((int64_t)ref_idx[p] * g.nkx + kx) * nky;
+    cfloat* outn = T2n + ((int64_t)p * g.nkx + kx) * (2 * nstore);
+    const float wgt = kx == 0 ? 1.f : 2.f;
+    wf2 a[16], B[2][8];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+      a[n1] = wf2{0.f, 0.f};
+      if (n1 < 2 || n1 >= 14) {
+        const int kyi = kept_index(64 * n1 + tl, H, g.kyp, g.kyn);
+        if (kyi >= 0) {
+          const cfloat v = cscale(cmulc(ref[kyi], cur[kyi]), scale);
+          a[n1] = wf2{v.x, -v.y};
+        }
+      }
+    }
+    wf_dft16(a);
+    wf10_passes_ab(a, tl, slab, tw_col, B);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int k1 = tl & 15, k2 = (tl >> 4) + 4 * b;
+      wf2 c[8];
+#pragma unroll
+      for (int n3 = 0; n3 < 8; ++n3) c[n3] = slab[wf10_x2(k1, k2, n3)];
+      wf_sync();
+      wf_dft8(c);
+#pragma unroll
+      for (int k3 = 0; k3 < 8; ++k3) {
+        const int y = k1 + 16 * k2 + 128 * k3;
+        const int yn = y < nstore ? y : y - (H - 2 * nstore);
+        if (yn >= 0 && yn < 2 * nstore && (y < nstore || y >= H - nstore)) outn[yn] = cmake(c[k3].x, -c[k3].y);
+        acc[8 * b + k3] += wgt * __builtin_amdgcn_sqrtf(c[k3].x * c[k3].x + c[k3].y * c[k3].y);
+      }
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int k3 = 0; k3 < 8; ++k3)
+      atomicAdd(&bounds[(int64_t)p * H + (t & 15) + 16 * ((t >> 4) + 4 * b) + 128 * k3], acc[8 * b + k3]);
+}
+
 // ------------------------------------------------------------------ K3: columns inverse
 // pair p: cur spectrum index cur_idx[p] in S_cur, ref spectrum index ref_idx[p] in S_ref.
 // MODE 0: conj(ref)*cur (cross-correlation); MODE 1: cur * phase ramp (Fourier shift,
@@ -1652,7 +1720,11 @@ int mc_xc_correlate_argmax(const void* S_cur, const int* cur_idx, const void* S_
   float* bounds = part_val + (int64_t)npairs * ngrp;  // npairs * H row bounds
   hipLaunchKernelGGL(xc_search_init, dim3((npairs * g.H + 255) / 256), dim3(256), 0, st, best, gate, bounds,
                      npairs, npairs * g.H);
-  if (g.H == 4096 && g.kyp <= 512 && g.kyn <= 512 && g_col_engine == 0) {
+  if (g.H == 1024 && g.kyp <= 128 && g.kyn <= 128 && g_col_engine == 0) {
+    hipLaunchKernelGGL(xc_cols_inv_near_wave1024, dim3((g.nkx + 4 * XC_NEAR_COLS_W - 1) / (4 * XC_NEAR_COLS_W), npairs),
+                       dim3(256), 0, st, (const cfloat*)S_cur, cur_idx, (const cfloat*)S_ref, ref_idx,
+                       (cfloat*)T2_near, bounds, (const cfloat*)tw_col, scale, g, nstore);
+  } else if (g.H == 4096 && g.kyp <= 512 && g.kyn <= 512 && g_col_engine == 0) {
     hipLaunchKernelGGL((xc_cols_inv_near<12, true>), dim3((g.nkx + XC_NEAR_COLS - 1) / XC_NEAR_COLS, npairs),
                        dim3(MC_WG), 0, st, (const cfloat*)S_cur, cur_idx, (const cfloat*)S_ref, ref_idx,
                        (cfloat*)T2_near, bounds, (const cfloat*)tw_col, scale, g, nstore);
