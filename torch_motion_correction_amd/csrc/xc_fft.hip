@@ -771,6 +771,7 @@ __global__ __launch_bounds__(MC_WG) void xc_cols_fwd(const cfloat* __restrict__ 
 // K2: only the kept output rows are produced (k3 in {0, 7} of the last radix-8 pass).
 // K3: only the kept input rows are fetched (n1 in {0, 1, 14, 15} of the first radix-16 pass);
 //     the inverse runs the forward kernel on conjugated data.
+#define XC_FWDW_COLS 1  // columns per wavefront in xc_cols_fwd_wave1024 (4 measured slower: the kernel streams T1 at 3.2 TB/s)
 __device__ __forceinline__ void wf10_passes_ab(wf2 (&a)[16], int t, wf2* slab, const cfloat* __restrict__ tw,
                                                wf2 (&B)[2][8]) {
   wf_twiddle16(a, wf_from(tw[t]), wf_from(tw[2 * t]), wf_from(tw[4 * t]), wf_from(tw[8 * t]));
@@ -803,17 +804,23 @@ __global__ __launch_bounds__(256) void xc_cols_fwd_wave1024(const cfloat* __rest
                                                             const cfloat* __restrict__ Mhat) {
   constexpr int H = 1024;
   __shared__ __attribute__((aligned(16))) wf2 slabs[4][WF10_N];
-  const int t = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int kx = blockIdx.x * 4 + wv, job = blockIdx.y;
-  if (kx >= g.nkx) return;  // no workgroup barrier below
+  const int kx0 = (blockIdx.x * 4 + wv) * XC_FWDW_COLS, job = blockIdx.y;
+  if (kx0 >= g.nkx) return;  // no workgroup barrier below
   wf2* slab = slabs[wv];
   const int nky = g.kyp + g.kyn;
+  const float dmean = fix ? fix[0] : 0.f, rstd = fix ? fix[1] : 1.f;
+#pragma unroll 1
+  for (int cc = 0; cc < XC_FWDW_COLS; ++cc) {
+  const int kx = kx0 + cc;
+  if (kx >= g.nkx) break;  // wave-uniform
+  int tq = threadIdx.x & 63;  // opaque per column: nothing derived from it is hoisted (registers)
+  asm volatile("" : "+v"(tq));
+  const int t = tq;
   const cfloat* col = T1 + ((int64_t)job * g.nkx + kx) * g.ny;
   cfloat* out = S + ((int64_t)job * g.nkx + kx) * nky;
   const float* f = filt ? filt + (int64_t)kx * nky : nullptr;
   const cfloat* mh = fix ? Mhat + (int64_t)kx * nky : nullptr;
-  const float dmean = fix ? fix[0] : 0.f, rstd = fix ? fix[1] : 1.f;
   wf2 a[16], B[2][8];
 #pragma unroll
   for (int n1 = 0; n1 < 16; ++n1) {
@@ -831,6 +838,7 @@ __global__ __launch_bounds__(256) void xc_cols_fwd_wave1024(const cfloat* __rest
       const wf2 v = slab[wf10_x2(k1, k2, n3)];
       if (n3 & 1) o[n3 >> 1] = v; else e[n3 >> 1] = v;
     }
+    wf_sync();
     wf_dft8_pruned<1>(e, o, z);  // k3 = 0 and 7
     const int c = k1 + 16 * k2;  // ky = c (k3 = 0) and c + 896 (k3 = 7)
 #pragma unroll
@@ -848,6 +856,7 @@ __global__ __launch_bounds__(256) void xc_cols_fwd_wave1024(const cfloat* __rest
         out[kyi] = f ? cscale(v, f[kyi]) : v;
       }
     }
+  }
   }
 }
 
@@ -1576,7 +1585,8 @@ int mc_xc_cols_forward_fix(const void* T1, const float* filt, void* S, const voi
   if (!T1 || !S || !tw_col || njobs < 1 || (fix && !Mhat)) return MC_ERR_ARG;
   dim3 grid(g.nkx, njobs);
   if (g.H == 1024 && g.kyp <= 128 && g.kyn <= 128 && g_col_engine == 0) {
-    hipLaunchKernelGGL(xc_cols_fwd_wave1024, dim3((g.nkx + 3) / 4, njobs), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(xc_cols_fwd_wave1024, dim3((g.nkx + 4 * XC_FWDW_COLS - 1) / (4 * XC_FWDW_COLS), njobs),
+                       dim3(256), 0, (hipStream_t)stream,
                        (const cfloat*)T1, filt, (cfloat*)S, (const cfloat*)tw_col, g, fix,
                        (const cfloat*)Mhat);
     return mc_check_launch();
