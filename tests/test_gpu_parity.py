@@ -482,9 +482,11 @@ def test_rigid_warp_odd_widths(mc, dev, shape):
 
 
 @pytest.mark.parametrize("t,h,w,ps", [(6, 96, 120, 1.0), (5, 100, 64, 1.0), (4, 64, 100, 1.3),
-                                      (5, 250, 372, 1.0), (3, 124, 126, 0.9)])
+                                      (5, 250, 372, 1.0), (3, 124, 126, 0.9), (3, 1000, 4096, 1.0)])
 def test_global_estimate_on_arbitrary_even_sizes(mc, dev, t, h, w, ps):
-    """chirp-z rows and/or columns: integer shifts must equal the oracle's exactly"""
+    """chirp-z rows and/or columns: integer shifts must equal the oracle's exactly.
+    (3, 1000, 4096): wave-per-row K1 with a mask support of 760 rows (47 full 16-row
+    workgroups + a tail of 8) feeding chirp-z columns."""
     st, _, _ = drift_stack(t, h, w, seed=h * 7 + w)
     got = mc.estimate_global_motion(st.to(dev), ps).cpu()
     ref, ccs = oracle.estimate_global_motion(st, ps, return_cc=True)
