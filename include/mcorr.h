@@ -71,6 +71,14 @@ int mc_xc_rows_forward(const float* src, const int64_t* job_off, int64_t row_str
                        const int* job_expo, const float* mask, const float* mean_rstd, void* T1,
                        const void* tw_row, int njobs, const mc_xc_geom* geom, void* stream);
 
+/* Input conditioning of raw detector frames (caller-side steps of the reference's pipeline,
+ * examples/ttMotion.py:90-121 gain multiply and :174-199 per-frame mean-zero):
+ * out[f] = raw[f] * gain - mean(raw[f] * gain), fp32 out.  kind: storage type of raw, 0 = u8,
+ * 1 = i16, 2 = f16, 3 = f32; gain: (h*w) floats or NULL; mean_zero != 0 needs `sums`
+ * (nframes doubles of scratch).  hw = pixels per frame. */
+int mc_condition_movie(const void* raw, int kind, const float* gain, int nframes, int64_t hw,
+                       int mean_zero, double* sums, float* out, void* stream);
+
 /* Dose-weighted accumulation in Fourier space (the caller-side exposure filter of the
  * reference's pipeline, examples/ttMotion.py:331-351, crit_exposure_bfactor = -1):
  * A[kx][ky] (+)= sum_j q_{frame0+j}(k) * S[j][kx][ky] over the nframes full spectra in S

@@ -841,3 +841,27 @@ def test_patches_1024_near_window_search_with_sub_pixel(mc, dev, strategy):
                                                                 reference_strategy=strategy)
     assert torch.equal(got[True][1], opos)
     assert float((got[True][0] - of).abs().max()) <= 1e-4
+
+
+# ------------------------------------------------------------------ N2: input conditioning
+
+
+@pytest.mark.parametrize("dtype", [torch.uint8, torch.int16, torch.float16, torch.float32])
+def test_condition_movie_matches_the_example_pipeline(mc, dev, dtype):
+    """gain multiply + per-frame mean-zero (examples/ttMotion.py:90-121, 174-199) straight from
+    the storage type, against the example's numpy arithmetic."""
+    g = torch.Generator().manual_seed(3)
+    raw = (torch.rand(3, 70, 90, generator=g) * 40).to(dtype)
+    gain = torch.rand(70, 90, generator=g) * 0.4 + 0.8
+    got = mc.condition_movie(raw.to(dev), gain.to(dev)).cpu()
+    x = raw.float().numpy().astype(np.float64) * gain.numpy().astype(np.float64)
+    ref = torch.from_numpy((x - x.mean(axis=(1, 2), keepdims=True)).astype(np.float32))
+    assert got.dtype == torch.float32 and got.shape == ref.shape
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    assert float(got.mean(dim=(1, 2)).abs().max()) < 1e-4
+    plain = mc.condition_movie(raw.to(dev), None, mean_zero=False).cpu()
+    assert torch.equal(plain, raw.float())
+    with pytest.raises(TypeError):
+        mc.condition_movie(raw.double().to(dev))
+    with pytest.raises(ValueError):
+        mc.condition_movie(raw.to(dev), gain[:10].to(dev))

@@ -4,6 +4,7 @@ teamtomo/torch-motion-correction: same public function names and signatures
 behind a C ABI (include/mcorr.h, libmcorr.so).  There is no CPU fallback."""
 
 from .api import (  # noqa: F401
+    condition_movie,
     correct_motion,
     correct_motion_fast,
     dose_weighted_sum,
@@ -31,6 +32,7 @@ __all__ = [
     "estimate_motion",
     "motion_correct_sum",
     "dose_weighted_sum",
+    "condition_movie",
     "evaluate_deformation_field_at_t",
     "resample_deformation_field",
     "image_shifts_to_deformation_field",

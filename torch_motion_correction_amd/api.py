@@ -216,6 +216,18 @@ def motion_correct_sum(image, deformation_grid, pixel_spacing, grid_type="catmul
     return (total.to(out_dev), frames.to(out_dev)) if return_frames else total.to(out_dev)
 
 
+def condition_movie(movie, gain=None, mean_zero=True, device=None):
+    """Raw detector frames -> the fp32 stack the estimators expect: ``movie * gain`` (a (h,w)
+    multiplicative gain reference, already flipped / rotated as needed) and, per frame,
+    minus its own mean -- the ``gain_correct`` and ``set_frames_mean_zero`` steps of the
+    reference's pipeline (examples/ttMotion.py:90-121, 174-199) done on the device straight
+    from uint8 / int16 / float16 / float32 storage.  (The example's hot-pixel step replaces
+    outliers by a RANDOM neighbour and has no deterministic counterpart here.)"""
+    out_dev = _out_device(movie, device)
+    dev = require_gpu(out_dev)
+    return engine.condition_movie(movie.detach().to(dev), gain, bool(mean_zero)).to(out_dev)
+
+
 def dose_weighted_sum(movie, pixel_spacing, dose_per_frame, pre_exposure=0.0, voltage=300.0, device=None):
     """``sum_f irfft2(q_f * rfft2(frame_f))`` with the Grant & Grigorieff exposure filter
     ``q_f = exp(-0.5 N_f / N_c(|k|))`` normalised by ``sqrt(sum_f q_f^2)``: the reference

@@ -2,6 +2,7 @@
 // All arithmetic that decides *which* pixels/bins are inside follows the fp32 op
 // order of the torch expressions the reference evaluates, without FMA contraction.
 #pragma clang fp contract(off)
+#include <hip/hip_fp16.h>
 #include "mc_common.h"
 #include "mcorr.h"
 
@@ -145,6 +146,55 @@ __global__ void dose_accumulate_kernel(const float2* __restrict__ S, int nframes
   A[i] = a;
 }
 
+// ------------------------------------------------------------------ input conditioning
+// The caller-side preparation of the reference's pipeline (examples/ttMotion.py:90-121 gain
+// multiply, :174-199 per-frame mean-zero) for raw detector frames of any storage type:
+//   out[f] = raw[f] * gain - mean(raw[f] * gain)      (fp32 out; gain / mean-zero optional)
+// pass 1 accumulates the per-frame sums in double, pass 2 applies.  KIND: 0 u8, 1 i16, 2 f16, 3 f32.
+template <int KIND>
+__device__ __forceinline__ float cond_load(const void* p, int64_t i) {
+  if (KIND == 0) return (float)reinterpret_cast<const unsigned char*>(p)[i];
+  if (KIND == 1) return (float)reinterpret_cast<const short*>(p)[i];
+  if (KIND == 2) return __half2float(reinterpret_cast<const __half*>(p)[i]);
+  return reinterpret_cast<const float*>(p)[i];
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void cond_sum_kernel(const void* __restrict__ raw,
+                                                       const float* __restrict__ gain, int64_t hw,
+                                                       double* __restrict__ sums) {
+  const int f = blockIdx.y;
+  const int64_t base = (int64_t)f * hw;
+  double s = 0.0;
+  float ps = 0.f;
+  int n = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (int64_t)gridDim.x * 256) {
+    const float v = cond_load<KIND>(raw, base + i) * (gain ? gain[i] : 1.f);
+    ps += v;
+    if (++n == 16) {  // flush the fp32 partial regularly
+      s += ps; ps = 0.f; n = 0;
+    }
+  }
+  s += ps;
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  __shared__ double part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&sums[f], (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void cond_apply_kernel(const void* __restrict__ raw,
+                                                         const float* __restrict__ gain, int64_t hw,
+                                                         const double* __restrict__ sums,
+                                                         float* __restrict__ out) {
+  const int f = blockIdx.y;
+  const int64_t base = (int64_t)f * hw;
+  const float mean = sums ? (float)(sums[f] / (double)hw) : 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (int64_t)gridDim.x * 256)
+    out[base + i] = cond_load<KIND>(raw, base + i) * (gain ? gain[i] : 1.f) - mean;
+}
+
 // ------------------------------------------------------------------ statistics
 __global__ __launch_bounds__(256) void box_stats_partial(const float* __restrict__ stack, int h,
                                                          int w, int hl, int hu, int wl, int wu,
@@ -266,6 +316,34 @@ int mc_dose_accumulate(const void* S, int nframes, int frame0, int total_frames,
   hipLaunchKernelGGL(dose_accumulate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, (const float2*)S, nframes, frame0, total_frames, (float2*)A, W,
                      H, nkx, pixel_size, pre_exposure, dose_per_frame, vscale, first, last);
+  return mc_check_launch();
+}
+
+int mc_condition_movie(const void* raw, int kind, const float* gain, int nframes, int64_t hw,
+                       int mean_zero, double* sums, float* out, void* stream) {
+  if (!raw || !out || nframes < 1 || hw < 1 || kind < 0 || kind > 3 || (mean_zero && !sums))
+    return MC_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  int64_t blocks = (hw + 256 * 8 - 1) / (256 * 8);
+  if (blocks > 2048) blocks = 2048;
+  dim3 grid((unsigned)blocks, nframes);
+#define MC_COND(K)                                                                                   \
+  do {                                                                                               \
+    if (mean_zero) hipLaunchKernelGGL(cond_sum_kernel<K>, grid, dim3(256), 0, st, raw, gain, hw, sums); \
+    hipLaunchKernelGGL(cond_apply_kernel<K>, grid, dim3(256), 0, st, raw, gain, hw,                  \
+                       mean_zero ? (const double*)sums : (const double*)nullptr, out);               \
+  } while (0)
+  if (mean_zero) {
+    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * nframes, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  switch (kind) {
+    case 0: MC_COND(0); break;
+    case 1: MC_COND(1); break;
+    case 2: MC_COND(2); break;
+    default: MC_COND(3); break;
+  }
+#undef MC_COND
   return mc_check_launch();
 }
 

@@ -506,6 +506,29 @@ def dose_weighted_sum(img, pixel_spacing, dose_per_frame, pre_exposure=0.0, volt
     return out[0]
 
 
+_RAW_KINDS = {torch.uint8: 0, torch.int16: 1, torch.float16: 2, torch.float32: 3}
+
+
+def condition_movie(raw, gain=None, mean_zero=True):
+    """raw (t,h,w) u8 / i16 / f16 / f32 on the GPU -> fp32 frames: x * gain, minus the frame's
+    own mean (examples/ttMotion.py:90-121, 174-199), in two passes over the raw bytes."""
+    lib = _lib.load()
+    if raw.dtype not in _RAW_KINDS:
+        raise TypeError(f"unsupported raw frame type {raw.dtype}; use uint8, int16, float16 or float32")
+    t, h, w = raw.shape
+    dev = raw.device
+    raw = raw.contiguous()
+    if gain is not None:
+        if tuple(gain.shape) != (h, w):
+            raise ValueError(f"gain reference has shape {tuple(gain.shape)}, frames are {(h, w)}")
+        gain = gain.to(device=dev, dtype=torch.float32).contiguous()
+    out = torch.empty((t, h, w), dtype=torch.float32, device=dev)
+    sums = torch.empty(t, dtype=torch.float64, device=dev) if mean_zero else None
+    check(lib.mc_condition_movie(ptr(raw), _RAW_KINDS[raw.dtype], ptr(gain), t, h * w, 1 if mean_zero else 0,
+                                 ptr(sums), ptr(out), stream_ptr(dev)), "mc_condition_movie")
+    return out
+
+
 def sum_frames(frames):
     lib = _lib.load()
     t, h, w = frames.shape
