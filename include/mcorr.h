@@ -114,6 +114,10 @@ int mc_xc_col_engine(int mode);
  * 1 = always one workgroup per row.  Process-wide; results agree to fp32 rounding. */
 int mc_xc_row_engine(int mode);
 
+/* m0 = {mean of the n floats at x, 1, 1}: the provisional mean mc_xc_rows_forward_stats takes
+ * (one small workgroup; any value near the true mean serves). */
+int mc_xc_provisional_mean(const float* x, int n, float* m0, void* stream);
+
 /* K1 with the normalisation statistics fused in (whole-frame jobs only): samples become
  * (x - m0[0]) * mask (m0: device float[3] = {provisional mean, 1, 1}); while reading, the
  * sums of (x-m0) and (x-m0)^2 over the central box rows [hl,hu) x cols [wl,wu) (window
@@ -142,6 +146,9 @@ int mc_xc_cols_inverse(const void* S_cur, const int* cur_idx, const void* S_ref,
                        const int* ref_idx, void* T2, const void* tw_col, float scale, int npairs,
                        const mc_xc_geom* geom, void* stream);
 
+/* Rows stored per end of the map by the near-window search below (searched rows + guard rows). */
+int mc_xc_near_rows(const mc_xc_geom* geom);
+
 /* K3+K4+K5 for the arg-max search without materialising the map or T2 (power-of-two
  * W and H >= 256; estimate_motion_xc.py:106-123).  Rows [0, n) and [H-n, H) of the
  * correlation map (n = mc_xc_near_rows(geom)) are transformed from T2_near
@@ -153,13 +160,15 @@ int mc_xc_cols_inverse(const void* S_cur, const int* cur_idx, const void* S_ref,
  * guard rows, so that nb (optional, [p][3][3] floats: the map around every peak as
  * mc_xc_peak_neighbourhood gives it, for the sub-pixel parabola fit of
  * estimate_motion_xc.py:414-483) can be taken from T2_near too.  part_val: npairs*(H/RG) +
- * npairs*H floats; part_idx: npairs*(H/RG) + npairs + 1 ints. */
-int mc_xc_near_rows(const mc_xc_geom* geom);
+ * npairs*H floats; part_idx: npairs*(H/RG) + npairs + 1 ints.
+ * shift_rows (optional): pair p's shift goes to row shift_rows[p] of a (n_shift_rows, 2) table
+ * that is zeroed first (rows no pair writes -- the reference frame -- stay exactly zero,
+ * estimate_motion_xc.py:102); NULL: shifts is (npairs, 2), row p. */
 int mc_xc_correlate_argmax(const void* S_cur, const int* cur_idx, const void* S_ref,
                            const int* ref_idx, void* T2_full, void* T2_near, float* part_val,
-                           int* part_idx, int* peaks, float* shifts, float* nb,
-                           const void* tw_col, const void* tw_row, float scale, int npairs,
-                           const mc_xc_geom* geom, void* stream);
+                           int* part_idx, int* peaks, float* shifts, const int* shift_rows,
+                           int n_shift_rows, float* nb, const void* tw_col, const void* tw_row,
+                           float scale, int npairs, const mc_xc_geom* geom, void* stream);
 
 /* K4+K5.  Inverse real row FFT of T2 fused with the arg-max (first maximum, as
  * torch.argmax): peaks[p] = flat index y*W+x, shifts[p] = (sy,sx) after the

@@ -54,7 +54,8 @@ SIGNATURES = {
     "mc_xc_cols_inverse": [vp, vp, vp, vp, vp, vp, f32, i32, GP, vp],
     "mc_xc_rows_inverse_argmax": [vp, vp, vp, vp, vp, vp, i32, GP, vp],
     "mc_xc_near_rows": [GP],
-    "mc_xc_correlate_argmax": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, i32, GP, vp],
+    "mc_xc_correlate_argmax": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, f32, i32, GP, vp],
+    "mc_xc_provisional_mean": [vp, i32, vp, vp],
     "mc_xc_peak_neighbourhood": [vp, vp, vp, vp, i32, GP, vp],
     "mc_xc_ref_mean_except_current": [vp, vp, vp, vp, vp, vp, i32, i32, i64, f32, vp],
     "mc_field_accumulate": [vp, vp, vp, i32, i32, i32, i32, f32, f32, i32, vp, vp],

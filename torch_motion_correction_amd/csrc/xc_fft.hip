@@ -655,6 +655,23 @@ __global__ __launch_bounds__(256) void xc_rows_fwd_wave512(
   }
 }
 
+// Provisional mean of the fused-statistics path: m0 = {mean of n samples, 1, 1} by ONE
+// workgroup (any value near the true mean keeps the linear fix-up free of cancellation).
+__global__ __launch_bounds__(256) void xc_provisional_mean_kernel(const float* __restrict__ x, int n,
+                                                                  float* __restrict__ m0) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)x[i];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  __shared__ double part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m0[0] = (float)(((part[0] + part[1]) + (part[2] + part[3])) / (double)n);
+    m0[1] = 1.f;
+    m0[2] = 1.f;
+  }
+}
+
 // (sum, sumsq) of (x - m0) over `count` samples, spread over XC_STAT_SLOTS accumulators
 // -> fix = {mean - m0, 1/std}, out3 = {mean, 1/std, std}  (unbiased std, as
 // torch.std_mean, utils.py:81)
@@ -1093,9 +1110,10 @@ __global__ __launch_bounds__(MC_WG) void xc_cols_inv_near(
 
 // best[p] = order(-inf), gate = 0, bounds = 0 in one launch
 __global__ void xc_search_init(int* __restrict__ best, int* __restrict__ gate, float* __restrict__ bounds,
-                               int npairs, int nbounds) {
+                               int npairs, int nbounds, float* __restrict__ shift_table, int nshift) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nbounds) bounds[i] = 0.f;
+  if (i < nshift) shift_table[i] = 0.f;  // rows no pair writes (the reference frame) stay zero
   if (i < npairs) best[i] = (int)0x807fffffu;  // float_order(-INFINITY) = 0xff800000 ^ 0x7fffffff
   if (i == 0) gate[0] = 0;
 }
@@ -1307,7 +1325,7 @@ __global__ __launch_bounds__(MC_WG) void xc_rows_inv(const cfloat* __restrict__ 
 // (xc.py:116-121: p if p <= n//2 else p - n).
 __global__ void xc_peak_final(const float* __restrict__ part_val, const int* __restrict__ part_idx,
                               int ngrp, int H, int W, int* __restrict__ peaks,
-                              float* __restrict__ shifts) {
+                              float* __restrict__ shifts, const int* __restrict__ shift_rows) {
   const int p = blockIdx.x;
   float bv = -INFINITY;
   int bi = 0x7fffffff;
@@ -1322,8 +1340,9 @@ __global__ void xc_peak_final(const float* __restrict__ part_val, const int* __r
     if (bi == 0x7fffffff) bi = 0;
     peaks[p] = bi;
     const int py = bi / W, px = bi - py * W;
-    shifts[2 * p] = (float)(py <= H / 2 ? py : py - H);
-    shifts[2 * p + 1] = (float)(px <= W / 2 ? px : px - W);
+    const int row = shift_rows ? shift_rows[p] : p;  // scatter into a per-frame table when asked
+    shifts[2 * row] = (float)(py <= H / 2 ? py : py - H);
+    shifts[2 * row + 1] = (float)(px <= W / 2 ? px : px - W);
   }
 }
 
@@ -1551,6 +1570,12 @@ int mc_xc_rows_forward(const float* src, const int64_t* job_off, int64_t row_str
                            nullptr, nullptr, stream);
 }
 
+int mc_xc_provisional_mean(const float* x, int n, float* m0, void* stream) {
+  if (!x || !m0 || n < 1) return MC_ERR_ARG;
+  hipLaunchKernelGGL(xc_provisional_mean_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n, m0);
+  return mc_check_launch();
+}
+
 int mc_xc_rows_forward_stats(const float* src, const int64_t* job_off, int64_t row_stride,
                              const float* mask, const float* m0, void* T1, const void* tw_row,
                              int njobs, const mc_xc_geom* q, int hl, int hu, int wl, int wu,
@@ -1691,7 +1716,7 @@ int mc_xc_rows_inverse_argmax(const void* T2, float* part_val, int* part_idx, in
   rc = mc_check_launch();
   if (rc) return rc;
   hipLaunchKernelGGL(xc_peak_final, dim3(npairs), dim3(64), 0, (hipStream_t)stream, part_val,
-                     part_idx, ngrp, g.H, g.W, peaks, shifts);
+                     part_idx, ngrp, g.H, g.W, peaks, shifts, (const int*)nullptr);
   return mc_check_launch();
 }
 
@@ -1706,9 +1731,9 @@ int mc_xc_near_rows(const mc_xc_geom* q) {
 
 int mc_xc_correlate_argmax(const void* S_cur, const int* cur_idx, const void* S_ref,
                            const int* ref_idx, void* T2_full, void* T2_near, float* part_val,
-                           int* part_idx, int* peaks, float* shifts, float* nb, const void* tw_col,
-                           const void* tw_row, float scale, int npairs, const mc_xc_geom* q,
-                           void* stream) {
+                           int* part_idx, int* peaks, float* shifts, const int* shift_rows,
+                           int n_shift_rows, float* nb, const void* tw_col, const void* tw_row,
+                           float scale, int npairs, const mc_xc_geom* q, void* stream) {
   XcGeom g;
   int rc = geom_from(q, &g, true, true);
   if (rc) return rc;
@@ -1728,8 +1753,9 @@ int mc_xc_correlate_argmax(const void* S_cur, const int* cur_idx, const void* S_
   int* best = part_idx + (int64_t)npairs * ngrp;  // npairs running maxima, then the gate word
   int* gate = best + npairs;
   float* bounds = part_val + (int64_t)npairs * ngrp;  // npairs * H row bounds
+  if (shift_rows && n_shift_rows < 1) return MC_ERR_ARG;
   hipLaunchKernelGGL(xc_search_init, dim3((npairs * g.H + 255) / 256), dim3(256), 0, st, best, gate, bounds,
-                     npairs, npairs * g.H);
+                     npairs, npairs * g.H, shifts, shift_rows ? 2 * n_shift_rows : 0);
   if (g.H == 1024 && g.kyp <= 128 && g.kyn <= 128 && g_col_engine == 0) {
     hipLaunchKernelGGL(xc_cols_inv_near_wave1024, dim3((g.nkx + 4 * XC_NEAR_COLS_W - 1) / (4 * XC_NEAR_COLS_W), npairs),
                        dim3(256), 0, st, (const cfloat*)S_cur, cur_idx, (const cfloat*)S_ref, ref_idx,
@@ -1783,7 +1809,7 @@ int mc_xc_correlate_argmax(const void* S_cur, const int* cur_idx, const void* S_
     if (rc) return rc;
   }
   hipLaunchKernelGGL(xc_peak_final, dim3(npairs), dim3(64), 0, st, part_val, part_idx, ngrp, g.H, g.W,
-                     peaks, shifts);
+                     peaks, shifts, shift_rows);
   if (nb) {  // 3 x 3 values around every peak (sub-pixel refinement), from whichever buffer holds the rows
     MC_DISPATCH_LOG(logn, {
       hipLaunchKernelGGL(xc_peak_nbhd<L>, dim3(3, npairs), dim3(MC_WG), 0, st, (const cfloat*)T2_full,
@@ -2239,7 +2265,7 @@ int mc_xcg_rows_inverse(const void* T2, float* part_val, int* part_idx, int* pea
   rc = mc_check_launch();
   if (rc) return rc;
   hipLaunchKernelGGL(xc_peak_final, dim3(npairs), dim3(64), 0, (hipStream_t)stream, part_val, part_idx,
-                     ngrp, g.H, g.W, peaks, shifts);
+                     ngrp, g.H, g.W, peaks, shifts, (const int*)nullptr);
   return mc_check_launch();
 }
 

@@ -131,13 +131,16 @@ def _forward_spectra(src, job_off, row_stride, job_expo, pl, stats, use_mask=Tru
     return (S, Sb) if dual else S
 
 
-def _peaks(S_cur, cur_idx, S_ref, ref_idx, pl, want_nbhd):
-    """K3+K4(+K6) for all pairs -> peaks (npairs,) int32, shifts (npairs,2), nb or None."""
+def _peaks(S_cur, cur_idx, S_ref, ref_idx, pl, want_nbhd, shift_rows=None, n_shift_rows=0):
+    """K3+K4(+K6) for all pairs -> peaks (npairs,) int32, shifts (npairs,2), nb or None.
+    With `shift_rows` (int32, one row index per pair) the shifts are scattered into a zeroed
+    (n_shift_rows, 2) table instead (rows no pair writes stay exactly zero)."""
     lib = _lib.load()
     g, dev = pl.geom, S_cur.device
     npairs = int(cur_idx.numel())
     peaks = torch.empty(npairs, dtype=torch.int32, device=dev)
-    shifts = torch.empty((npairs, 2), dtype=torch.float32, device=dev)
+    shifts = torch.empty((n_shift_rows if shift_rows is not None else npairs, 2), dtype=torch.float32,
+                         device=dev)
     nb = torch.empty((npairs, 3, 3), dtype=torch.float32, device=dev) if want_nbhd else None
     per_pair = g.nkx * g.H * 8
     chunk = max(1, min(npairs, WORKSPACE_BYTES // per_pair))
@@ -150,6 +153,9 @@ def _peaks(S_cur, cur_idx, S_ref, ref_idx, pl, want_nbhd):
     # near-window search (+ the 3x3 neighbourhood of the peak when asked): the full map (T2) is
     # a device-side fallback that normally never runs (mc_xc_correlate_argmax)
     fused = FUSED_SEARCH and _pow2(g.W) and _pow2(g.H) and g.H >= 1024
+    scatter = shift_rows is not None and fused and chunk >= npairs  # one call zeroes + fills the table
+    if shift_rows is not None and not scatter:
+        table, shifts = shifts, torch.empty((npairs, 2), dtype=torch.float32, device=dev)
     if fused:
         T2n = torch.empty((chunk, g.nkx, 2 * lib.mc_xc_near_rows(g), 2), dtype=torch.float32, device=dev)
     for a in range(0, npairs, chunk):
@@ -157,7 +163,10 @@ def _peaks(S_cur, cur_idx, S_ref, ref_idx, pl, want_nbhd):
         if fused:
             check(lib.mc_xc_correlate_argmax(ptr(S_cur), ptr(cur_idx[a : a + n]), ptr(S_ref),
                                              ptr(ref_idx[a : a + n]), ptr(T2), ptr(T2n), ptr(pv), ptr(pi),
-                                             ptr(peaks[a : a + n]), ptr(shifts[a : a + n]),
+                                             ptr(peaks[a : a + n]),
+                                             ptr(shifts) if scatter else ptr(shifts[a : a + n]),
+                                             ptr(shift_rows) if scatter else None,
+                                             n_shift_rows if scatter else 0,
                                              ptr(nb[a : a + n]) if want_nbhd else None, ptr(pl.tw_col),
                                              ptr(pl.tw_row), scale, n, g, st), "mc_xc_correlate_argmax")
             continue
@@ -185,6 +194,10 @@ def _peaks(S_cur, cur_idx, S_ref, ref_idx, pl, want_nbhd):
             check(lib.mc_xc_peak_neighbourhood(ptr(T2), ptr(peaks[a : a + n]), ptr(nb[a : a + n]),
                                                ptr(pl.tw_row), n, g, st),
                   "mc_xc_peak_neighbourhood")
+    if shift_rows is not None and not scatter:  # general path: scatter with torch
+        table.zero_()
+        table[shift_rows.long()] = shifts
+        shifts = table
     return peaks, shifts, nb
 
 
@@ -221,10 +234,9 @@ def _global_spectra(img, pl):
     # provisional mean m0 keeps the linear fix-up free of cancellation; any value near the
     # true mean does, so one row of frame 0's box is enough (one small workgroup)
     acc = torch.empty(128, dtype=torch.float64, device=dev)  # 64 x {sum, sumsq}
-    m0 = torch.ones(3, dtype=torch.float32, device=dev)
-    check(lib.mc_central_box_stats(ptr(img), 1, h, w, hl, hl + 1, wl, wu, ptr(acc), ptr(m0), st),
-          "mc_central_box_stats")
-    m0[1:].fill_(1.0)
+    m0 = torch.empty(3, dtype=torch.float32, device=dev)
+    check(lib.mc_xc_provisional_mean(C.c_void_p(img.data_ptr() + 4 * (hl * w + wl)), wu - wl, ptr(m0), st),
+          "mc_xc_provisional_mean")
     fix = torch.empty(2, dtype=torch.float32, device=dev)
     out3 = torch.empty(3, dtype=torch.float32, device=dev)
     T1 = torch.empty((t, g.nkx, g.ny, 2), dtype=torch.float32, device=dev)
@@ -247,14 +259,13 @@ def global_shifts(img, reference_frame, pixel_spacing, b_factor, frequency_range
     cur = [f for f in range(t) if f != reference_frame]
     if not cur:
         return torch.zeros((t, 2), dtype=torch.float32, device=dev)
-    cur_idx, ref_idx, scatter = _cached(
+    cur_idx, ref_idx = _cached(
         ("global_pairs", str(dev), t, reference_frame),
-        lambda: (_i32(cur, dev), _i32([reference_frame] * len(cur), dev),
-                 _i64([cur.index(f) if f != reference_frame else len(cur) for f in range(t)], dev)))
-    _, shifts, _ = _peaks(S, cur_idx, S, ref_idx, pl, want_nbhd=False)
-    # row `len(cur)` of the padded table is the zero shift of the reference frame itself
-    padded = torch.cat([shifts, shifts.new_zeros((1, 2))], dim=0)
-    return padded.index_select(0, scatter)
+        lambda: (_i32(cur, dev), _i32([reference_frame] * len(cur), dev)))
+    # pair p = frame cur[p]: its shift goes to row cur[p] of the (t, 2) table; the reference
+    # frame's row is written by nobody and stays exactly zero
+    _, shifts, _ = _peaks(S, cur_idx, S, ref_idx, pl, want_nbhd=False, shift_rows=cur_idx, n_shift_rows=t)
+    return shifts
 
 
 # ------------------------------------------------------------------ a8: patch field
