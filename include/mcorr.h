@@ -270,6 +270,9 @@ typedef struct mc_xc_line {
   const void* chirp;
   const void* bspec;
   int M;
+  int keep; /* 0: classic plan.  > 0 (mc_xcg_rows_forward only): output-pruned plan -- only
+               outputs k < keep and k > n - keep are exact, which needs M >= n + 2 keep - 1 only;
+               bspec = FFT_M of conj(chirp) wrapped over the offsets (-(n-1) - (keep-1) .. keep-1) / M */
 } mc_xc_line;
 
 /* Same contracts and layouts as mc_xc_rows_forward / mc_xc_cols_forward /

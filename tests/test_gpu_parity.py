@@ -482,9 +482,11 @@ def test_rigid_warp_odd_widths(mc, dev, shape):
 
 
 @pytest.mark.parametrize("t,h,w,ps", [(6, 96, 120, 1.0), (5, 100, 64, 1.0), (4, 64, 100, 1.3),
-                                      (5, 250, 372, 1.0), (3, 124, 126, 0.9), (3, 1000, 4096, 1.0)])
+                                      (5, 250, 372, 1.0), (3, 124, 126, 0.9), (3, 1000, 4096, 1.0),
+                                      (3, 200, 1440, 1.0)])
 def test_global_estimate_on_arbitrary_even_sizes(mc, dev, t, h, w, ps):
     """chirp-z rows and/or columns: integer shifts must equal the oracle's exactly.
+    (3, 200, 1440): the output-pruned chirp-z row plan (M = 1024 instead of 2048).
     (3, 1000, 4096): wave-per-row K1 with a mask support of 760 rows (47 full 16-row
     workgroups + a tail of 8) feeding chirp-z columns."""
     st, _, _ = drift_stack(t, h, w, seed=h * 7 + w)
@@ -496,14 +498,17 @@ def test_global_estimate_on_arbitrary_even_sizes(mc, dev, t, h, w, ps):
             assert torch.equal(got[:, f], ref[:, f]), (f, got[:, f].flatten(), ref[:, f].flatten())
 
 
-def test_pruned_spectrum_on_arbitrary_sizes(dev):
+@pytest.mark.parametrize("h,w,pruned_m", [(100, 120, False), (64, 1440, True), (64, 1442, True), (72, 2880, True)])
+def test_pruned_spectrum_on_arbitrary_sizes(dev, h, w, pruned_m):
+    """pruned_m: the forward row pass runs the output-pruned chirp-z plan (half the circular length)."""
     from torch_motion_correction_amd import engine, plan
 
     g = torch.Generator().manual_seed(31)
-    h, w = 100, 120
     img = torch.randn(3, h, w, generator=g)
     pl = plan.get_xc_plan(h, w, 1.0, 500.0, (300, 10), dev)
     gm = pl.geom
+    line, _ = plan.line_plan(w // 2, -1, dev, keep=gm.nkx + 1)
+    assert (line.keep > 0 and line.M < plan.bluestein_size(w // 2)) == pruned_m
     d = img.to(dev)
     off = torch.arange(3, device=dev, dtype=torch.int64) * (h * w)
     S = torch.view_as_complex(engine._forward_spectra(d, off, w, None, pl, engine.central_box_stats(d)).cpu())

@@ -30,7 +30,8 @@ class XcGeom(C.Structure):
 class XcLine(C.Structure):
     """mirror of ``mc_xc_line`` (Bluestein line plan: device pointers + M)"""
 
-    _fields_ = [("tw_m", C.c_void_p), ("chirp", C.c_void_p), ("bspec", C.c_void_p), ("M", C.c_int)]
+    _fields_ = [("tw_m", C.c_void_p), ("chirp", C.c_void_p), ("bspec", C.c_void_p), ("M", C.c_int),
+                ("keep", C.c_int)]
 
 
 GP = C.POINTER(XcGeom)

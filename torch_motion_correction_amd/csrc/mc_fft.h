@@ -330,17 +330,30 @@ __device__ __forceinline__ void wg_fft_inplace(cfloat* line, int tid, const cflo
 // by 1/M).  load(j) -> x[j] for j < n (each j once); store(k, X[k]) is called for every
 // k < M, the caller keeps the k it needs (k < n).  Every thread of the workgroup must call
 // it; `line` must be free on entry; on exit a barrier is still needed before reusing `line`.
+// keep > 0: output-pruned form.  Only the outputs k in [0, keep) and (n - keep, n) are wanted, so
+// the circular convolution only has to be exact there: M >= n + 2 keep - 1 is enough (instead
+// of 2n - 1), provided bspec was built for that wrap (plan.line_plan(keep=...)): output k < keep
+// sits at position k, output n - m (1 <= m < keep) at position M - m.
 template <int M, typename Load, typename Store>
 __device__ __forceinline__ void wg_bluestein(cfloat* line, int tid, const cfloat* __restrict__ tw_m,
                                              const cfloat* __restrict__ chirp,
                                              const cfloat* __restrict__ bspec, int n, Load load,
-                                             Store store) {
+                                             Store store, int keep = 0) {
   auto in1 = [&](int j) { return j < n ? cmul(load(j), chirp[j]) : cmake(0.f, 0.f); };
   auto out1 = [&](int j, cfloat v) { line[lpad(j)] = cmul(v, bspec[j]); };
   wg_fft<M, -1>(line, tid, tw_m, 1, in1, out1);
   __syncthreads();
   auto in2 = [&](int j) { return line[lpad(j)]; };
-  auto out2 = [&](int k, cfloat v) {
+  auto out2 = [&](int p, cfloat v) {
+    int k = p;
+    if (keep > 0) {
+      if (p > M - keep) {
+        k = p - M + n;
+        if (n & 1) v = cmake(-v.x, -v.y);  // the convolution ran at offset k - n: chirp(k - n) = (-1)^n chirp(k)
+      } else if (p >= keep) {
+        return;
+      }
+    }
     if (k < n) store(k, cmul(v, chirp[k]));
   };
   wg_fft_inplace<M, +1>(line, tid, tw_m, 1, in2, out2);

@@ -1874,6 +1874,7 @@ struct XcLine {
   const cfloat* chirp;  // n entries
   const cfloat* bspec;  // M entries
   int n;                // transform length (W/2 for rows, H for columns)
+  int keep;             // > 0: output-pruned plan (wg_bluestein), only xcg_rows_fwd takes it
 };
 
 template <int LOGM>
@@ -1918,7 +1919,7 @@ __global__ __launch_bounds__(MC_WG) void xcg_rows_fwd(
       if (k < g.nkx) zlo[k] = v;
       if (k > 0 && n - k <= g.nkx) zhi[n - k] = v;
     };
-    wg_bluestein<M>(line, tid, ln.tw_m, ln.chirp, ln.bspec, n, load, store);
+    wg_bluestein<M>(line, tid, ln.tw_m, ln.chirp, ln.bspec, n, load, store, ln.keep);
     __syncthreads();
     for (int k = tid; k < g.nkx; k += MC_WG) {
       const cfloat zk = (k < n) ? zlo[k] : zlo[0];                  // Z[n] == Z[0]
@@ -2133,11 +2134,19 @@ static int geom_from_g(const mc_xc_geom* q, XcGeom* g) {
   return MC_OK;
 }
 
-static int line_from(const mc_xc_line* l, int n, XcLine* out, int* logm) {
+// allow_keep: the caller's kernel understands output-pruned plans (keep > 0, M >= n + 2 keep - 1)
+static int line_from(const mc_xc_line* l, int n, XcLine* out, int* logm, bool allow_keep = false,
+                     int need_keep = 0) {
   if (!l || !l->tw_m || !l->chirp || !l->bspec) return MC_ERR_ARG;
-  if (!mc_is_pow2(l->M) || l->M < 32 || l->M > 8192 || l->M < 2 * n - 1) return MC_ERR_UNSUPPORTED;
+  if (!mc_is_pow2(l->M) || l->M < 32 || l->M > 8192) return MC_ERR_UNSUPPORTED;
+  if (l->keep < 0 || (l->keep > 0 && !allow_keep)) return MC_ERR_ARG;
+  if (l->keep > 0) {
+    if (l->keep < need_keep || l->M < n + 2 * l->keep - 1) return MC_ERR_ARG;
+  } else if (l->M < 2 * n - 1) {
+    return MC_ERR_UNSUPPORTED;
+  }
   out->tw_m = (const cfloat*)l->tw_m; out->chirp = (const cfloat*)l->chirp;
-  out->bspec = (const cfloat*)l->bspec; out->n = n;
+  out->bspec = (const cfloat*)l->bspec; out->n = n; out->keep = l->keep;
   *logm = mc_ilog2(l->M);
   return MC_OK;
 }
@@ -2154,7 +2163,8 @@ int mc_xcg_rows_forward(const float* src, const int64_t* job_off, int64_t row_st
   XcGeom g; XcLine ln; int logm;
   int rc = geom_from_g(q, &g);
   if (rc) return rc;
-  if ((rc = line_from(line, g.W / 2, &ln, &logm))) return rc;
+  // rows forward needs Z[k] for k < nkx and Z[n - k] for 1 <= k <= nkx: keep >= nkx + 1
+  if ((rc = line_from(line, g.W / 2, &ln, &logm, true, g.nkx + 1))) return rc;
   if (!src || !job_off || !T1 || !tw_row || njobs < 1) return MC_ERR_ARG;
   const size_t lds = sizeof(cfloat) * ((size_t)lds_len(line->M) + 2 * (g.nkx + 1) + (size_t)g.nkx * (g.RG + 1));
   if (lds > 160 * 1024) return MC_ERR_ARG;

@@ -73,7 +73,7 @@ def _k1(lib, g, dev, src, off, row_stride, expo, mask, stats, T1, tw_row, n, st)
     if _pow2(g.W):
         return lib.mc_xc_rows_forward(ptr(src), ptr(off), row_stride, ptr(expo), ptr(mask), ptr(stats),
                                       ptr(T1), ptr(tw_row), n, g, st)
-    line, _ = planmod.line_plan(g.W // 2, -1, dev)
+    line, _ = planmod.line_plan(g.W // 2, -1, dev, keep=g.nkx + 1)  # output-pruned when that shrinks M
     return lib.mc_xcg_rows_forward(ptr(src), ptr(off), row_stride, ptr(expo), ptr(mask), ptr(stats),
                                    ptr(T1), ptr(tw_row), line, n, g, st)
 

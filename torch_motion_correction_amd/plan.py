@@ -72,7 +72,7 @@ def xc_geometry(h: int, w: int, high: float, radius: float, smoothing: float) ->
         rg = 16
     else:  # chirp-z rows: one line of M = pow2 >= 2*(w/2)-1 points + two small side buffers
         subgroups = 1
-        m = bluestein_size(n_line)
+        m = min(bluestein_size(n_line), bluestein_size_for(n_line + 2 * (nkx + 1) - 1))  # line_plan(keep=nkx+1)
         lines = (m + (m >> 4) + 1) + 2 * (nkx + 1)
         rg = 4
     while rg > subgroups and 8 * (lines + nkx * (rg + 1)) > (LDS_BUDGET if _is_pow2(w) else 150 * 1024):
@@ -92,38 +92,53 @@ def full_geometry(h: int, w: int) -> XcGeom:
     return xc_geometry(h, w, high=10.0, radius=float(max(h, w)), smoothing=0.0)
 
 
-def bluestein_size(n: int) -> int:
+def bluestein_size_for(length: int) -> int:
     m = 32
-    while m < 2 * n - 1:
+    while m < length:
         m *= 2
     return m
+
+
+def bluestein_size(n: int) -> int:
+    return bluestein_size_for(2 * n - 1)
 
 
 _LINES: dict = {}
 
 
-def line_plan(n: int, direction: int, device):
+def line_plan(n: int, direction: int, device, keep: int = 0):
     """Chirp-z tables for a length-n transform (any n), direction -1 forward / +1 inverse:
     chirp[j] = exp(direction * i*pi*j^2/n) with j^2 reduced mod 2n in integers, bspec =
-    FFT_M(wrapped conj(chirp)) / M.  Returns (XcLine, keep-alive tensors)."""
-    key = (str(device), n, direction)
+    FFT_M(wrapped conj(chirp)) / M.  Returns (XcLine, keep-alive tensors).
+
+    keep > 0: output-pruned plan for the forward row pass.  Only outputs k in [0, keep) and
+    (n - keep, n) are wanted, i.e. signed k in (-keep, keep); with inputs j in [0, n) the
+    convolution only touches offsets k - j in (-(n-1) - (keep-1) .. keep-1), so a circular
+    length M >= n + 2 keep - 1 suffices (4096 instead of 8192 for 5760-wide frames)."""
+    keep = int(keep)
+    if keep > 0 and bluestein_size_for(n + 2 * keep - 1) >= bluestein_size(n):
+        keep = 0  # nothing to gain: same circular length as the classic plan
+    key = (str(device), n, direction, keep)
     if key in _LINES:
         return _LINES[key]
-    m = bluestein_size(n)
+    m = bluestein_size_for(n + 2 * keep - 1) if keep > 0 else bluestein_size(n)
     if m > 8192:
         raise NotImplementedError(f"transform length {n}: chirp-z needs M={m} > 8192")
-    j = np.arange(n, dtype=np.int64)
-    ang = direction * np.pi * ((j * j) % (2 * n)).astype(np.float64) / n
-    chirp = np.exp(1j * ang)
-    b = np.conj(chirp)
+    chirp_at = lambda j: np.exp(1j * direction * np.pi * ((j * j) % (2 * n)).astype(np.float64) / n)
+    chirp = chirp_at(np.arange(n, dtype=np.int64))
     bw = np.zeros(m, dtype=np.complex128)
-    bw[:n] = b
-    if n > 1:
-        bw[m - n + 1:] = b[1:][::-1]
+    if keep > 0:
+        off = np.arange(-(n - 1) - (keep - 1), keep, dtype=np.int64)  # every offset k - j that occurs
+        bw[off % m] = np.conj(chirp_at(off))
+    else:
+        b = np.conj(chirp)
+        bw[:n] = b
+        if n > 1:
+            bw[m - n + 1:] = b[1:][::-1]
     bspec = np.fft.fft(bw) / m
     to_dev = lambda z: torch.from_numpy(np.stack([z.real, z.imag], -1).astype(np.float32)).to(device)
     tw_m, ch, bs = get_twiddles(m, device), to_dev(chirp), to_dev(bspec)
-    line = XcLine(tw_m=tw_m.data_ptr(), chirp=ch.data_ptr(), bspec=bs.data_ptr(), M=m)
+    line = XcLine(tw_m=tw_m.data_ptr(), chirp=ch.data_ptr(), bspec=bs.data_ptr(), M=m, keep=keep)
     _LINES[key] = (line, (tw_m, ch, bs))
     return _LINES[key]
 
