@@ -413,7 +413,7 @@ struct RigidArgs {
   float* out_frames;
   float* out_sum;
   int tiles_x, tiles_y;
-  int frames_in_grid;  // 1: blockIdx.y selects the frame (no fused sum)
+  int frames_in_grid;  // c > 0: blockIdx.y selects a chunk of c frames (no fused sum); 0: all frames in-block
 };
 
 #pragma clang fp contract(fast)
@@ -448,8 +448,8 @@ __global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES, RIGID_MINW) void warp_rig
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[r][k] = 0.f;
 
-  const int f_lo = a.frames_in_grid ? (int)blockIdx.y : 0;
-  const int f_hi = a.frames_in_grid ? f_lo + 1 : a.nframes;
+  const int f_lo = a.frames_in_grid ? (int)blockIdx.y * a.frames_in_grid : 0;
+  const int f_hi = a.frames_in_grid ? min(f_lo + a.frames_in_grid, a.nframes) : a.nframes;
 
   float4 pre[RIGID_QPT];
   auto fetch = [&](int f) {  // issue the tile loads of frame f into `pre`
@@ -532,7 +532,10 @@ __global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES, RIGID_MINW) void warp_rig
     for (int rr = 0; rr < RIGID_ROWS + 4; ++rr) {
       // keep at most two rows of LDS reads in flight: without this the scheduler hoists
       // all 96 reads and the kernel needs > 240 VGPRs
-      if ((rr & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+  #ifndef RIGID_SB
+#define RIGID_SB 2
+#endif
+    if (RIGID_SB > 0 && (rr % RIGID_SB) == 0) __builtin_amdgcn_sched_barrier(0);
       const float* src = wrow + rr * RIGID_RSTRIDE;
       float v[8];
 #pragma unroll
@@ -593,39 +596,46 @@ __global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES, RIGID_MINW) void warp_rig
 #pragma clang fp contract(fast)
 // ------------------------------------------------------------------ rigid warp, LDS-DMA
 // Same mathematics as warp_rigid; the 36 x 272 input window of a tile goes HBM -> LDS by
-// `global_load_lds_dwordx4` (no VGPR staging, row-major image), double-buffered so the
-// DMA of frame f+1 runs under the arithmetic of frame f with ONE barrier per frame.  A lane
-// reads its 8-float window as three aligned 16-byte LDS reads; the window's misalignment
-// m = (x_tile + Sx - 1) mod 4 is frame-uniform, so the tap selection is resolved at
-// compile time in four specialisations of the strip body.  Columns outside the image
-// (border padding = clipped tap coordinate) are patched in LDS for edge tiles only.
+// `global_load_lds_dwordx4` (no VGPR staging, row-major image).  The global side of that
+// DMA only needs 4-byte alignment, so the window starts exactly at column x_tile + Sx - 1:
+// a lane's 8-float window is two aligned 16-byte LDS reads whatever the shift, and there
+// is ONE strip body (four misalignment specialisations of it were 24 KB of straight-line
+// code, which thrashed the instruction cache once blocks of different frames shared a CU,
+// and cost 16 more VGPRs: the fused-sum kernel now fits 4 workgroups per CU).
+// Default: single buffer, 4 workgroups per CU cover each other's DMA latency.  NBUF = 2
+// double-buffers inside the workgroup (2 per CU) and leaves the row stores of frame f in
+// flight under frame f+1.  Columns outside the image (border padding = clipped tap
+// coordinate) are re-fetched element-wise for edge tiles only.
 // Requires w % 4 == 0 and 16-byte aligned frames (host checks; else warp_rigid).
 #define RD_QUADS_PAD (((RIGID_NQ + 63) / 64) * 64)  // DMA granule: 64 lanes x 16 B
 typedef __attribute__((address_space(3))) void* lds_vptr;
 
-template <bool WRITE_FRAMES, bool WRITE_SUM, int M>
+template <bool WRITE_FRAMES, bool WRITE_SUM, bool FULL>
 __device__ __forceinline__ void rigid_strip_dma(const RigidArgs& a, const float4* tile, int f,
                                                 int y0, int x0, int wave, int lane, float wyv,
                                                 const float (&wx)[5][4],
                                                 float (&acc)[RIGID_ROWS][4]) {
   const int h = a.h, w = a.w;
   const float4* wrow = tile + (wave * RIGID_ROWS) * RIGID_QUADS + lane;
+  // FULL: the whole 32 x 256 tile lies inside the image -> no per-row predicates, the strip is
+  // one basic block and the scheduler can run the LDS reads ahead of the arithmetic
+  float* orow = WRITE_FRAMES ? a.out_frames + (int64_t)f * h * w + (int64_t)y0 * w + x0 : nullptr;
   float H[5][4];
 #pragma unroll
   for (int rr = 0; rr < RIGID_ROWS + 4; ++rr) {
-    if ((rr & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+#ifndef RIGID_SB
+#define RIGID_SB 2
+#endif
+    if (RIGID_SB > 0 && (rr % (RIGID_SB > 0 ? RIGID_SB : 1)) == 0) __builtin_amdgcn_sched_barrier(0);
     const float4 q0 = wrow[rr * RIGID_QUADS], q1 = wrow[rr * RIGID_QUADS + 1];
-    float4 q2 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (M > 0) q2 = wrow[rr * RIGID_QUADS + 2];
-    const float e[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+    const float e[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
     float* Hn = H[rr % 5];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      Hn[k] = (((wx[0][k] * e[M + k] + wx[1][k] * e[M + k + 1]) + wx[2][k] * e[M + k + 2]) +
-               wx[3][k] * e[M + k + 3]) + wx[4][k] * e[M + k + 4];
+      Hn[k] = (((wx[0][k] * e[k] + wx[1][k] * e[k + 1]) + wx[2][k] * e[k + 2]) +
+               wx[3][k] * e[k + 3]) + wx[4][k] * e[k + 4];
     if (rr >= 4) {
       const int ro = rr - 4;
-      const int yo = y0 + ro;
       float wy[5];
 #pragma unroll
       for (int i = 0; i < 5; ++i)
@@ -636,10 +646,8 @@ __device__ __forceinline__ void rigid_strip_dma(const RigidArgs& a, const float4
         o[k] = (((wy[0] * H[(ro + 0) % 5][k] + wy[1] * H[(ro + 1) % 5][k]) +
                  wy[2] * H[(ro + 2) % 5][k]) + wy[3] * H[(ro + 3) % 5][k]) +
                wy[4] * H[(ro + 4) % 5][k];
-      if (yo < h && x0 < w) {
-        if (WRITE_FRAMES)
-          *reinterpret_cast<float4*>(a.out_frames + (int64_t)f * h * w + (int64_t)yo * w + x0) =
-              make_float4(o[0], o[1], o[2], o[3]);
+      if (FULL || (y0 + ro < h && x0 < w)) {
+        if (WRITE_FRAMES) *reinterpret_cast<float4*>(orow + (int64_t)ro * w) = make_float4(o[0], o[1], o[2], o[3]);
         if (WRITE_SUM) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) acc[ro][k] += o[k];
@@ -650,7 +658,7 @@ __device__ __forceinline__ void rigid_strip_dma(const RigidArgs& a, const float4
 }
 
 template <bool WRITE_FRAMES, bool WRITE_SUM, int NBUF>
-__global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES, NBUF == 1 ? ((WRITE_FRAMES && WRITE_SUM) ? 3 : 4) : 2)
+__global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES, NBUF == 1 ? 4 : 2)
 void warp_rigid_dma(RigidArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_rd[];
   float4* const b0 = reinterpret_cast<float4*>(smem_rd);
@@ -674,14 +682,15 @@ void warp_rigid_dma(RigidArgs a) {
   for (int r = 0; r < RIGID_ROWS; ++r)
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[r][k] = 0.f;
-  const int f_lo = a.frames_in_grid ? (int)blockIdx.y : 0;
-  const int f_hi = a.frames_in_grid ? f_lo + 1 : a.nframes;
+  const bool full_tile = yt + RIGID_WAVES * RIGID_ROWS <= h && xt + RIGID_LANES * 4 <= w;
+  const int f_lo = a.frames_in_grid ? (int)blockIdx.y * a.frames_in_grid : 0;
+  const int f_hi = a.frames_in_grid ? min(f_lo + a.frames_in_grid, a.nframes) : a.nframes;
 
   // DMA of one frame's window into `dst`: granule i = quads [64 i, 64 i + 64)
   auto dma = [&](int f, float4* dst) {
     const float* fr = a.frames + (int64_t)f * hw;
     const int Sy = a.S[2 * f], Sx = a.S[2 * f + 1];
-    const int ax = (xt + Sx - 1) & ~3;
+    const int ax = xt + Sx - 1;  // any multiple of 4 BYTES: the global side of the DMA needs no more
     for (int i = wave; i < RD_QUADS_PAD / 64; i += RIGID_WAVES) {
       int q = i * 64 + lane;
       q = q < RIGID_NQ ? q : RIGID_NQ - 1;  // tail lanes re-load the last quad into the pad
@@ -689,26 +698,30 @@ void warp_rigid_dma(RigidArgs a) {
       int r = yt + Sy - 1 + tr;
       r = r < 0 ? 0 : (r > h - 1 ? h - 1 : r);
       int c = ax + 4 * qc;
-      c = c < 0 ? 0 : (c > w - 4 ? w - 4 : c);  // whole quads: inside or clamped (patched later)
+      c = c < 0 ? 0 : (c > w - 4 ? w - 4 : c);  // whole quads inside the row; clamped ones are patched
       __builtin_amdgcn_global_load_lds(fr + (int64_t)r * w + c, (lds_vptr)(dst + i * 64), 16, 0, 0);
     }
   };
-  // border padding for edge tiles: element at column c outside [0,w) := element at the
-  // clipped column, which lies inside the same tile row
+  // border padding for edge tiles: a quad whose 4 columns are not all inside the row was
+  // DMA'd from a clamped address and holds the wrong columns; its elements are re-fetched
+  // one by one at their clipped column (a handful of quads per row, edge tiles only)
   auto patch = [&](int f, float4* t4) {
-    const int Sx = a.S[2 * f + 1];
-    const int ax = (xt + Sx - 1) & ~3;
+    const int Sy = a.S[2 * f], Sx = a.S[2 * f + 1];
+    const int ax = xt + Sx - 1;
     if (ax >= 0 && ax + 4 * RIGID_QUADS <= w) return false;
+    const float* fr = a.frames + (int64_t)f * hw;
     float* t = reinterpret_cast<float*>(t4);
-    for (int i = tid; i < RIGID_TROWS * 4 * RIGID_QUADS; i += RIGID_LANES * RIGID_WAVES) {
-      const int tr = i / (4 * RIGID_QUADS), e = i - tr * (4 * RIGID_QUADS);
-      const int c = ax + e;
-      if (c < 0 || c > w - 1) {
-        const int cc = c < 0 ? 0 : w - 1;
-        // the quad holding column cc was loaded at its own (clamped == true) address
-        int qsrc = (cc & ~3) - ax;  // tile-relative element index of that quad's first float
-        qsrc = qsrc < 0 ? 0 : (qsrc > 4 * (RIGID_QUADS - 1) ? 4 * (RIGID_QUADS - 1) : qsrc);
-        t[tr * 4 * RIGID_QUADS + e] = t[tr * 4 * RIGID_QUADS + qsrc + (cc & 3)];
+    for (int q = tid; q < RIGID_NQ; q += RIGID_LANES * RIGID_WAVES) {
+      const int tr = q / RIGID_QUADS, qc = q - tr * RIGID_QUADS;
+      const int s0 = ax + 4 * qc;
+      if (s0 >= 0 && s0 <= w - 4) continue;
+      int r = yt + Sy - 1 + tr;
+      r = r < 0 ? 0 : (r > h - 1 ? h - 1 : r);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int c = s0 + e;
+        c = c < 0 ? 0 : (c > w - 1 ? w - 1 : c);
+        t[4 * q + e] = fr[(int64_t)r * w + c];
       }
     }
     return true;
@@ -736,15 +749,16 @@ void warp_rigid_dma(RigidArgs a) {
   if (patch(f_lo, b0)) __syncthreads();
   int cur = 0;
   for (int f = f_lo; f < f_hi; ++f) {
-    if (NBUF == 2 && f + 1 < f_hi) dma(f + 1, cur ? b0 : b1);
-    const int m = (xt + a.S[2 * f + 1] - 1) & 3;
-    const float4* t = cur ? b1 : b0;
-    switch (m) {
-      case 0: rigid_strip_dma<WRITE_FRAMES, WRITE_SUM, 0>(a, t, f, y0, x0, wave, lane, wyv, wx, acc); break;
-      case 1: rigid_strip_dma<WRITE_FRAMES, WRITE_SUM, 1>(a, t, f, y0, x0, wave, lane, wyv, wx, acc); break;
-      case 2: rigid_strip_dma<WRITE_FRAMES, WRITE_SUM, 2>(a, t, f, y0, x0, wave, lane, wyv, wx, acc); break;
-      default: rigid_strip_dma<WRITE_FRAMES, WRITE_SUM, 3>(a, t, f, y0, x0, wave, lane, wyv, wx, acc); break;
+    if (NBUF == 2 && f + 1 < f_hi) {
+      // both kinds of loads for frame f+1 go out BEFORE this frame's stores: the vector-memory
+      // counter retires in order, so waiting for "all but the 8 newest" operations below waits for
+      // the loads and leaves this frame's 8 row stores draining under the next frame
+      dma(f + 1, cur ? b0 : b1);
+      load_weights(f + 1, wxn, wyvn);
     }
+    const float4* t = cur ? b1 : b0;
+    if (full_tile) rigid_strip_dma<WRITE_FRAMES, WRITE_SUM, true>(a, t, f, y0, x0, wave, lane, wyv, wx, acc);
+    else rigid_strip_dma<WRITE_FRAMES, WRITE_SUM, false>(a, t, f, y0, x0, wave, lane, wyv, wx, acc);
     if (f + 1 < f_hi) {
       if constexpr (NBUF == 1) {
         // single buffer, 4 workgroups per CU: other workgroups cover this one's latency,
@@ -756,8 +770,8 @@ void warp_rigid_dma(RigidArgs a) {
         __syncthreads();
         if (patch(f + 1, b0)) __syncthreads();
       } else {
-        load_weights(f + 1, wxn, wyvn);  // ordinary loads last: their wait also retires the DMA
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (WRITE_FRAMES && full_tile) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // RIGID_ROWS stores
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // DMA of f+1 landed for every wave; everyone is done with buf[cur]
         cur ^= 1;
         if (patch(f + 1, cur ? b1 : b0)) __syncthreads();
@@ -1311,8 +1325,14 @@ int mc_warp_rigid(const float* frames, int nframes, int h, int w, const float* s
   a.out_frames = out_frames; a.out_sum = out_sum;
   a.tiles_x = (w + RIGID_LANES * 4 - 1) / (RIGID_LANES * 4);
   a.tiles_y = (h + RIGID_WAVES * RIGID_ROWS - 1) / (RIGID_WAVES * RIGID_ROWS);
-  a.frames_in_grid = out_sum ? 0 : 1;  // without the fused sum every frame is its own block
-  dim3 grid(a.tiles_x * a.tiles_y, a.frames_in_grid ? nframes : 1), block(RIGID_LANES, RIGID_WAVES);
+  // Without the fused sum every frame is its own block: blocks are dispatched frame-major, so the
+  // resident ones always work on neighbouring tiles of ONE frame and halo rows / shared 128-byte
+  // lines hit in L2 (FETCH_SIZE 2.76 GB for 2.68 GB of frames).  With the sum a block keeps its
+  // tile's partial sums in registers over all frames; blocks drift apart in time and the same
+  // halos miss (3.7 GB) -- measured 0.97 ms vs 1.28 ms at 40 x 4096^2.
+  a.frames_in_grid = out_sum ? 0 : 1;
+  dim3 grid(a.tiles_x * a.tiles_y, a.frames_in_grid ? (nframes + a.frames_in_grid - 1) / a.frames_in_grid : 1),
+      block(RIGID_LANES, RIGID_WAVES);
   static int use_dma = -1;
   if (use_dma < 0) {
     const char* v = getenv("MC_RIGID_DMA");
