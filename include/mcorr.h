@@ -296,6 +296,32 @@ int mc_xcg_rows_inverse(const void* T2, float* part_val, int* part_idx, int* pea
 /* caller-side frame sum (examples/ttMotion.py:398): sum[h*w] = sum_t frames[t]. */
 int mc_sum_frames(const float* frames, int nframes, int64_t hw, float* sum, void* stream);
 
+/* ---- estimate_local_motion (estimate_motion_optimizer.py:28-439): loss + gradient ------
+ * The reference rebuilds, every iteration and for every patch, rfftn(patch * mask), the
+ * Fourier shift by the spline-predicted shifts, the band-pass and B-factor filters, the
+ * leave-one-out reference and the loss (:361-417, :466-514, :611-671), and differentiates
+ * it with autograd.  Here the masked + filtered patch spectra are computed once (pruned,
+ * layout of mc_xc_cols_forward: (npatch * t jobs, nkx, nky) complex, job = patch * t +
+ * frame) and an iteration is two passes over them.
+ * mc_local_loss_sums: for every patch b, bin tile and frame f (partial: (npatch, ntiles,
+ * t, 6) floats, to be summed over the tiles by the caller):
+ *   [0] sum h fy Im(conj(S) G_f)   [1] same with fx   [2] sum h |t G_f - S|^2
+ *   [3] sum h Re(G_f conj(S - G_f))   [4] sum h |S - G_f|^2   [5] sum h |G_f|^2
+ * with G_f = P_f exp(-2 pi i (fy sy_f + fx sx_f)), S = sum_f G_f, shifts_px (npatch, t,
+ * 2) = (y, x) pixels, fy (nky) / fx (nkx) = the bins' frequencies in cycles/pixel, hx
+ * (nkx) = weight of column kx (NULL = 1; Hermitian multiplicities for the real-space
+ * losses).  Loss values and shift gradients of "mse", "cc" follow from these sums
+ * (csrc/local_motion.hip header); "ncc" needs mc_local_ncc_grad with ab (npatch, t, 2) =
+ * (dL/dn_f, dL/dey_f) -> partial (npatch, ntiles, t, 2) = sum h f{y,x} Im(V_f G_f).
+ * 1 <= t <= 512. */
+int mc_local_loss_tiles(int nkx, int nky, int* ntiles);
+int mc_local_loss_sums(const void* spectra, const float* shifts_px, const float* fy, const float* fx,
+                       const float* hx, int npatch, int t, int nkx, int nky, float* partial,
+                       void* stream);
+int mc_local_ncc_grad(const void* spectra, const float* shifts_px, const float* fy, const float* fx,
+                      const float* hx, const float* ab, int npatch, int t, int nkx, int nky,
+                      float* partial, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

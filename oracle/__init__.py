@@ -41,3 +41,8 @@ from oracle.motion import (  # noqa: F401
     prepare_bandpass_filter,
     resample_deformation_field,
 )
+from oracle.local_motion import (  # noqa: F401,E402
+    LocalMotionProblem,
+    OptimizationTracker,
+    estimate_local_motion,
+)

@@ -269,11 +269,61 @@ def oracle_vectors():
     print("wrote oracle_*.npz")
 
 
+def reference_local_motion_vectors():
+    """tests/golden/reference_local_helpers.npz: the torch-only pieces of the reference's
+    estimate_local_motion path, run from the reference's own modules (inert stubs for the absent
+    packages, as above): _compute_loss (estimate_motion_optimizer.py:611-671), the optimiser
+    defaults of _setup_optimizer (:517-608), ImagePatchIterator's patches and normalised centres
+    in lattice order (patch_utils.py:47-192) and OptimizationTracker (optimization_state.py)."""
+    import json
+
+    _reference_modules_behind_inert_stubs()
+    emo = importlib.import_module("torch_motion_correction.estimate_motion_optimizer")
+    pu = importlib.import_module("torch_motion_correction.patch_utils")
+    ost = importlib.import_module("torch_motion_correction.optimization_state")
+    pgm = importlib.import_module("torch_motion_correction.patch_grid")
+    g = torch.Generator().manual_seed(77)
+    out = {}
+    b, t, ph, pw = 2, 3, 8, 10
+    x = torch.fft.rfftn(torch.randn(b, t, ph, pw, generator=g), dim=(-2, -1))
+    y = torch.fft.rfftn(torch.randn(b, t, ph, pw, generator=g), dim=(-2, -1))
+    out["loss_x"], out["loss_y"] = torch.view_as_real(x).numpy(), torch.view_as_real(y).numpy()
+    for lt in ("mse", "ncc", "cc"):
+        out[f"loss_{lt}"] = emo._compute_loss(x, y, ph, pw, loss_type=lt).numpy()
+    defaults = {}
+    for name in ("adam", "sgd", "rmsprop", "lbfgs"):
+        opt = emo._setup_optimizer(name, [torch.zeros(2, requires_grad=True)])
+        defaults[name] = {k: (list(v) if isinstance(v, tuple) else v) for k, v in opt.defaults.items()
+                          if isinstance(v, (int, float, bool, str, tuple, type(None)))}
+        defaults[name]["class"] = type(opt).__name__
+    out["optimizer_defaults_json"] = np.frombuffer(json.dumps(defaults, sort_keys=True).encode(), dtype=np.uint8)
+    img = torch.randn(3, 40, 52, generator=g)
+    pts = pgm.patch_grid_centers(image_shape=(3, 40, 52), patch_shape=(1, 16, 20), patch_step=(1, 8, 10),
+                                 distribute_patches=True)
+    it = pu.ImagePatchIterator(image=img, patch_size=(16, 20), control_points=pts)
+    patches, centers = [], []
+    for pb, cb in it.get_iterator(batch_size=4, randomized=False):
+        patches.append(pb)
+        centers.append(cb)
+    out["ipi_image"], out["ipi_points"] = img.numpy(), pts.numpy()
+    out["ipi_patches"] = torch.cat(patches, 0).numpy()  # (npatch, t, ph, pw)
+    out["ipi_centers"] = torch.cat(centers, 1).numpy()  # (t, npatch, 3) normalised
+    out["ipi_batch_sizes"] = np.asarray([p.shape[0] for p in patches])
+    tr = ost.OptimizationTracker(sample_every_n_steps=3, total_steps=8)
+    for step in range(8):
+        if tr.sample_this_step(step):
+            tr.add_checkpoint(torch.full((2, 1, 1, 2), float(step)), 0.5 * step, step)
+    out["tracker_json"] = np.frombuffer(json.dumps(tr.as_dict(), sort_keys=True).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "reference_local_helpers.npz"), **out)
+    print("wrote reference_local_helpers.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     if os.path.isdir(REF_SRC):
         reference_vectors()
         reference_helper_vectors()
+        reference_local_motion_vectors()
     else:
         print("reference not present: patch_grid_reference.npz not regenerated")
     oracle_vectors()

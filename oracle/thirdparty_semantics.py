@@ -153,7 +153,7 @@ def _weights(t, M):
     return tv @ M  # (b,4)
 
 
-def cubic_spline_grid_3d(data, u, grid_type):
+def cubic_spline_grid_3d(data, u, grid_type, differentiable=False):
     """Evaluate a (c, nt, nh, nw) uniform cubic spline grid at u (..., 3) in [0,1]^3.
 
     Separable tricubic with the 4x4 basis matrix on [1,s,s^2,s^3]; the control
@@ -162,7 +162,7 @@ def cubic_spline_grid_3d(data, u, grid_type):
     Returns (..., c).
     """
     M = spline_matrix(grid_type)
-    data = data.detach().to(torch.float32).cpu()
+    data = (data if differentiable else data.detach()).to(torch.float32).cpu()  # grid data = the parameters
     lead = u.shape[:-1]
     uu = u.detach().reshape(-1, 3).to(torch.float32).cpu()
     for dim in (1, 2, 3):

@@ -870,3 +870,86 @@ def test_condition_movie_matches_the_example_pipeline(mc, dev, dtype):
         mc.condition_movie(raw.double().to(dev))
     with pytest.raises(ValueError):
         mc.condition_movie(raw.to(dev), gain[:10].to(dev))
+
+
+# ------------------------------------------------------------------ estimate_local_motion
+
+
+def _local_case(t=5, h=96, w=112, seed=5):
+    st, _, _ = drift_stack(t, h, w, seed=seed)
+    return st
+
+
+@pytest.mark.parametrize("loss_type", ["mse", "cc", "ncc"])
+@pytest.mark.parametrize("patch,res,grid_type", [((32, 32), (5, 2, 2), "catmull_rom"), ((32, 48), (3, 2, 3), "bspline")])
+def test_local_motion_loss_and_gradient_match_autograd_oracle(dev, loss_type, patch, res, grid_type):
+    """The HIP loss and its analytic gradient w.r.t. the spline parameters against the oracle's
+    autograd through rfftn -> Fourier shift -> filters -> leave-one-out reference -> loss
+    (estimate_motion_optimizer.py:361-417), at a non-trivial parameter point.  Tolerance: 2e-4 of
+    the largest gradient entry (fp32 phase of up to ~30 rad on both sides)."""
+    from torch_motion_correction_amd import local_motion
+
+    st = _local_case()
+    g = torch.Generator().manual_seed(11)
+    new = (torch.randn(2, *res, generator=g) * 1.5).requires_grad_(True)
+    init = torch.randn(2, *res, generator=g) * 0.7
+    oprob = oracle.LocalMotionProblem(st, 1.2, patch)
+    total = None
+    for a in range(0, oprob.npatch, 8):
+        l = oprob.batch_loss(new, init, grid_type, list(range(a, min(a + 8, oprob.npatch))), loss_type)
+        total = l if total is None else total + l
+    total.backward()
+    prob = local_motion.LocalMotionProblem(st.to(dev), 1.2, patch, res, grid_type)
+    assert (prob.gh, prob.gw) == (oprob.gh, oprob.gw)
+    sizes = np.minimum(8, prob.npatch - (np.arange(prob.npatch) // 8) * 8)
+    wb = torch.from_numpy(1.0 / sizes.astype(np.float64)).to(dev)
+    nd = new.detach().to(dev).requires_grad_(True)
+    loss = local_motion._Loss.apply(prob.shifts_px(nd, init.to(dev)), prob, wb, loss_type)
+    loss.backward()
+    lv, tv = loss.item(), total.item()
+    assert abs(lv - tv) <= 2e-4 * abs(tv), (lv, tv)
+    err = (nd.grad.cpu() - new.grad).abs().max() / new.grad.abs().max()
+    assert float(err) <= 2e-4, float(err)
+
+
+@pytest.mark.parametrize("optimizer_type,loss_type,n_it", [("adam", "mse", 4), ("sgd", "cc", 3), ("lbfgs", "mse", 3),
+                                                          ("rmsprop", "ncc", 3)])
+def test_local_motion_short_runs_follow_the_oracle(mc, dev, optimizer_type, loss_type, n_it):
+    """A few optimiser steps end to end, with an initial field and a trajectory.  Adam / RMSprop
+    normalise the gradient, which turns 1e-5 relative gradient differences into visible parameter
+    differences where a gradient entry is near zero, hence the looser bound (5 % of the step size)."""
+    st = _local_case(t=5, h=96, w=96, seed=9)
+    init = torch.randn(2, 5, 1, 1, generator=torch.Generator().manual_seed(2)) * 0.5
+    kw = dict(patch_shape=(32, 32), deformation_field_resolution=(5, 2, 2), initial_deformation_field=init,
+              n_iterations=n_it, optimizer_type=optimizer_type, loss_type=loss_type, return_trajectory=True)
+    ref, rtr = oracle.estimate_local_motion(st, 1.0, **kw)
+    got, gtr = mc.estimate_local_motion(st.to(dev), 1.0, **kw)
+    assert got.shape == ref.shape == (2, 5, 2, 2) and got.device.type == "cuda"
+    step = float((ref - (oracle.resample_deformation_field(init, (5, 2, 2)) - 0)).abs().max())
+    assert float((got.cpu() - ref).abs().max()) <= 0.05 * max(step, 1e-3)
+    assert [c.step for c in gtr.checkpoints] == [c.step for c in rtr.checkpoints]
+    for a, b in zip(gtr.checkpoints, rtr.checkpoints):
+        assert abs(a.loss - b.loss) <= 1e-3 * abs(b.loss) + 1e-9
+
+
+def test_local_motion_recovers_a_known_drift(mc, dev):
+    """Frames displaced by a known small per-frame shift (inside the basin of the 10-pixel band
+    limit): refinement from zero must find it.  frame_f(x) = base(x - d_f)  =>  field ~ d_f - mean."""
+    g = torch.Generator().manual_seed(21)
+    base = torch.randn(128 + 16, 128 + 16, generator=g)
+    dy, dx = [-2, -1, 0, 0, 1, 2], [1, 1, 0, 0, -1, -1]
+    st = torch.stack([base[8 - dy[f]:8 - dy[f] + 128, 8 - dx[f]:8 - dx[f] + 128]
+                      + 0.5 * torch.randn(128, 128, generator=g) for f in range(6)])
+    field = mc.estimate_local_motion(st.to(dev), 1.0, (64, 64), (6, 1, 1), None, n_iterations=150,
+                                     optimizer_kwargs={"lr": 0.05}).cpu()
+    mean = float(np.mean(dy + dx))
+    assert float((field[0, :, 0, 0] - (torch.tensor(dy, dtype=torch.float32) - mean)).abs().max()) < 0.35
+    assert float((field[1, :, 0, 0] - (torch.tensor(dx, dtype=torch.float32) - mean)).abs().max()) < 0.35
+
+
+def test_local_motion_argument_errors(mc, dev):
+    st = torch.randn(4, 64, 64, device=dev)
+    with pytest.raises(ValueError, match="Invalid grid type"):
+        mc.estimate_local_motion(st, 1.0, (32, 32), (4, 1, 1), grid_type="linear", n_iterations=1)
+    with pytest.raises(ValueError, match="Unsupported optimizer"):
+        mc.estimate_local_motion(st, 1.0, (32, 32), (4, 1, 1), optimizer_type="adagrad", n_iterations=1)

@@ -317,3 +317,99 @@ def test_oracle_pixel_shifts_match_the_reference(refh):
                             indexing="ij")
     got = motion.get_pixel_shifts(torch.zeros(37, 53), 1.3, refh["gps_lattice"], torch.stack([yy, xx], dim=-1))
     assert torch.equal(got, refh["gps_out"])
+
+
+# ------------------------------------------------------------------ estimate_local_motion
+
+
+@pytest.fixture(scope="module")
+def refl():
+    """tests/golden/reference_local_helpers.npz: produced by the REFERENCE's own torch-only
+    functions of the estimate_local_motion path (oracle/make_goldens.py:reference_local_motion_vectors)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_local_helpers.npz")
+    return np.load(path)
+
+
+def test_oracle_local_losses_match_the_reference(refl):
+    from oracle import local_motion as olm
+
+    x = torch.view_as_complex(torch.from_numpy(refl["loss_x"]))
+    y = torch.view_as_complex(torch.from_numpy(refl["loss_y"]))
+    for lt in ("mse", "ncc", "cc"):
+        got = olm.compute_loss(x, y, 8, 10, lt)
+        assert torch.equal(got, torch.from_numpy(refl[f"loss_{lt}"])), lt
+
+
+def test_oracle_and_product_optimiser_defaults_match_the_reference(refl):
+    import json
+
+    from oracle import local_motion as olm
+    from torch_motion_correction_amd import local_motion as plm
+
+    want = json.loads(bytes(refl["optimizer_defaults_json"]).decode())
+    for mod in (olm, plm):
+        for name, ref in want.items():
+            opt = mod.setup_optimizer(name, [torch.zeros(2, requires_grad=True)])
+            assert type(opt).__name__ == ref["class"]
+            for k, v in ref.items():
+                if k == "class":
+                    continue
+                have = opt.defaults[k]
+                assert (list(have) if isinstance(have, tuple) else have) == v, (name, k, have, v)
+        with pytest.raises(ValueError, match="Unsupported optimizer"):
+            mod.setup_optimizer("adagrad", [torch.zeros(2, requires_grad=True)])
+
+
+def test_oracle_patches_and_centres_match_the_reference_iterator(refl):
+    """ImagePatchIterator in lattice order (patch_utils.py): same pixels, same normalised centres."""
+    from oracle import patch_grid as pg
+
+    img = torch.from_numpy(refl["ipi_image"])
+    t, h, w = img.shape
+    ph, pw = 16, 20
+    centers = pg.centers_3d((t, h, w), (1, ph, pw), (1, ph // 2, pw // 2), True)
+    assert torch.equal(centers, torch.from_numpy(refl["ipi_points"]))
+    cn = centers.clone().float()
+    cn[..., 0] /= float(t - 1)
+    cn[..., 1] /= float(h - 1)
+    cn[..., 2] /= float(w - 1)
+    assert torch.equal(cn.reshape(t, -1, 3), torch.from_numpy(refl["ipi_centers"]))
+    pts = centers[0].reshape(-1, 3)
+    patches = torch.stack([img[:, int(c[1]) - ph // 2:int(c[1]) - ph // 2 + ph,
+                               int(c[2]) - pw // 2:int(c[2]) - pw // 2 + pw] for c in pts])
+    assert torch.equal(patches, torch.from_numpy(refl["ipi_patches"]))
+    n = patches.shape[0]
+    assert list(refl["ipi_batch_sizes"]) == [min(4, n - a) for a in range(0, n, 4)]
+
+
+def test_trackers_match_the_reference(refl):
+    import json
+
+    from oracle import local_motion as olm
+    from torch_motion_correction_amd import optimization_state as pos
+
+    want = json.loads(bytes(refl["tracker_json"]).decode())
+    for cls in (olm.OptimizationTracker, pos.OptimizationTracker):
+        tr = cls(sample_every_n_steps=3, total_steps=8)
+        for step in range(8):
+            if tr.sample_this_step(step):
+                tr.add_checkpoint(torch.full((2, 1, 1, 2), float(step)), 0.5 * step, step)
+        assert json.loads(json.dumps(tr.as_dict(), sort_keys=True)) == want
+
+
+def test_oracle_local_motion_recovers_a_small_drift():
+    g = torch.Generator().manual_seed(21)
+    base = torch.randn(96 + 16, 96 + 16, generator=g)
+    dy, dx = [-2, -1, 0, 1, 2], [1, 1, 0, -1, -1]
+    st = torch.stack([base[8 - dy[f]:8 - dy[f] + 96, 8 - dx[f]:8 - dx[f] + 96]
+                      + 0.5 * torch.randn(96, 96, generator=g) for f in range(5)])
+    f, tr = oracle.estimate_local_motion(st, 1.0, (64, 64), (5, 1, 1), None, n_iterations=120,
+                                         optimizer_kwargs={"lr": 0.05}, return_trajectory=True,
+                                         trajectory_kwargs={"sample_every_n_steps": 40})
+    mean = float(np.mean(dy + dx))
+    assert float((f[0, :, 0, 0] - (torch.tensor(dy, dtype=torch.float32) - mean)).abs().max()) < 0.4
+    assert float((f[1, :, 0, 0] - (torch.tensor(dx, dtype=torch.float32) - mean)).abs().max()) < 0.4
+    assert [c.step for c in tr.checkpoints] == [0, 40, 80, 119]
+    assert tr.checkpoints[-1].loss < tr.checkpoints[0].loss
+    with pytest.raises(ValueError, match="Invalid grid type"):
+        oracle.estimate_local_motion(st, 1.0, (64, 64), (5, 1, 1), grid_type="linear", n_iterations=1)

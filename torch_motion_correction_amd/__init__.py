@@ -9,6 +9,7 @@ from .api import (  # noqa: F401
     correct_motion_fast,
     dose_weighted_sum,
     estimate_global_motion,
+    estimate_local_motion,
     estimate_motion,
     estimate_motion_cross_correlation_patches,
     evaluate_deformation_field,
@@ -20,6 +21,7 @@ from .api import (  # noqa: F401
 )
 from ._lib import McorrError  # noqa: F401
 from .data_io import read_deformation_field_from_csv, write_deformation_field_to_csv  # noqa: F401
+from .optimization_state import OptimizationState, OptimizationTracker  # noqa: F401
 from .pipeline import MoviePipeline, MovieResult, motion_correct_movies  # noqa: F401
 
 __all__ = [
@@ -29,6 +31,9 @@ __all__ = [
     "evaluate_deformation_field",
     "estimate_global_motion",
     "estimate_motion_cross_correlation_patches",
+    "estimate_local_motion",
+    "OptimizationState",
+    "OptimizationTracker",
     "estimate_motion",
     "motion_correct_sum",
     "dose_weighted_sum",

@@ -240,6 +240,40 @@ def dose_weighted_sum(movie, pixel_spacing, dose_per_frame, pre_exposure=0.0, vo
                                     float(pre_exposure), float(voltage)).to(out_dev)
 
 
+def estimate_local_motion(image, pixel_spacing, patch_shape, deformation_field_resolution,
+                          initial_deformation_field=None, device=None, n_iterations=100, b_factor=500,
+                          frequency_range=(300, 10), optimizer_type="adam", grid_type="catmull_rom",
+                          loss_type="mse", optimizer_kwargs=None, return_trajectory=False,
+                          trajectory_kwargs=None):
+    """Refine a (2, nt, nh, nw) spline deformation field by gradient descent on the agreement of
+    Fourier-shifted patches with the mean of the other frames (estimate_motion_optimizer.py:28-439;
+    same arguments, defaults, return values and error messages).  The loss and its analytic
+    gradient are HIP kernels over patch spectra that are transformed once (local_motion.py)."""
+    from . import local_motion
+    from .optimization_state import OptimizationTracker
+
+    dev = _out_device(image, device)
+    img = _stage(image, dev)
+    if grid_type not in ("catmull_rom", "bspline"):
+        raise ValueError(f"Invalid grid type: {grid_type}. Must be 'catmull_rom' or 'bspline'.")
+    res = tuple(int(r) for r in deformation_field_resolution)
+    trajectory = None
+    if return_trajectory:
+        tk = trajectory_kwargs if trajectory_kwargs is not None else {}
+        tk.setdefault("sample_every_n_steps", 1)
+        tk.setdefault("total_steps", n_iterations)
+        trajectory = OptimizationTracker(**tk)
+    if initial_deformation_field is None:
+        init = torch.zeros((2, *res), dtype=torch.float32, device=dev)
+    else:
+        init = resample_deformation_field(_stage(initial_deformation_field.detach(), dev), res).contiguous()
+        init = init - torch.mean(init)
+    final = local_motion.estimate_local_motion(img, float(pixel_spacing), patch_shape, res, init, n_iterations,
+                                               b_factor, frequency_range, optimizer_type, grid_type, loss_type,
+                                               optimizer_kwargs, trajectory)
+    return (final, trajectory) if return_trajectory else final
+
+
 def _correct_motion_fast_impl(img_dev, deformation_grid, dev, mutate):
     if tuple(deformation_grid.shape[-2:]) != (1, 1):
         raise ValueError(

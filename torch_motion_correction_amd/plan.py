@@ -184,15 +184,18 @@ def circle_mask(h: int, w: int, radius: float, smoothing: float, device) -> torc
 
 
 def get_xc_plan(h: int, w: int, pixel_spacing: float, b_factor: float, frequency_range,
-                device) -> XcPlan:
+                device, mask_radius=None, mask_smoothing=None) -> XcPlan:
     """Plan for cross-correlating (h, w) windows: mask radius min(h,w)/4, soft edge
-    min(h,w)/8 (estimate_motion_xc.py:69-74 / :262-264)."""
-    key = (str(device), h, w, float(pixel_spacing), float(b_factor), tuple(map(float, frequency_range)))
+    min(h,w)/8 (estimate_motion_xc.py:69-74 / :262-264) unless given (estimate_local_motion
+    uses pw/4 and pw/4, estimate_motion_optimizer.py:162-167)."""
+    radius = min(h, w) / 4 if mask_radius is None else float(mask_radius)
+    smoothing = min(h, w) / 8 if mask_smoothing is None else float(mask_smoothing)
+    key = (str(device), h, w, float(pixel_spacing), float(b_factor), tuple(map(float, frequency_range)),
+           radius, smoothing)
     if key in _PLANS:
         return _PLANS[key]
     lib = _lib.load()
     low, high = band_limits(frequency_range, pixel_spacing)
-    radius, smoothing = min(h, w) / 4, min(h, w) / 8
     geom = xc_geometry(h, w, high, radius, smoothing)
     mask = circle_mask(h, w, radius, smoothing, device)
     filt = torch.empty((geom.nkx, geom.nky), dtype=torch.float32, device=device)
