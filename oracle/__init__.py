@@ -30,6 +30,8 @@ Pinning status (see DESIGN.md section "Oracle"):
 from oracle.motion import (  # noqa: F401
     correct_motion,
     correct_motion_fast,
+    correct_motion_slow,
+    correct_motion_two_grids,
     dose_weighted_sum,
     estimate_global_motion,
     estimate_motion_cross_correlation_patches,

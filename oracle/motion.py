@@ -126,6 +126,39 @@ def correct_motion(image, deformation_grid, pixel_spacing, grad=False, grid_type
     return torch.stack(out, dim=0)
 
 
+def correct_motion_two_grids(image, new_data, base_data, pixel_spacing, new_type="catmull_rom",
+                             base_type="catmull_rom"):
+    """correct_motion.py:188-299 -- both grids evaluated on the (10 gh, 10 gw) lattice of the NEW
+    grid at t_i, summed, then _correct_frame.  The grids are given by their control data + basis."""
+    image = image.float().cpu()
+    t = image.shape[0]
+    _, _, gh, gw = new_data.shape
+    out = []
+    with torch.no_grad():
+        for frame, ft in zip(image, torch.linspace(0, 1, steps=t)):
+            lat = (evaluate_deformation_field_at_t(new_data.float().cpu(), ft, (10 * gh, 10 * gw), new_type)
+                   + evaluate_deformation_field_at_t(base_data.float().cpu(), ft, (10 * gh, 10 * gw), base_type))
+            out.append(_correct_frame(frame, pixel_spacing, lat))
+    return torch.stack(out, dim=0)
+
+
+def correct_motion_slow(image, deformation_grid, grad=False, device=None):
+    """correct_motion.py:302-427 -- the field at every pixel (t_i, y/(h-1), x/(w-1)), Catmull-Rom,
+    used as PIXEL shifts; bicubic sample_image_2d of pixel + shift."""
+    image = image.float().cpu()
+    field = deformation_grid.float().cpu()
+    t, h, w = image.shape
+    pixel_grid = tp.coordinate_grid((h, w))
+    norm = pixel_grid / torch.as_tensor([h - 1, w - 1], dtype=torch.float32)
+    out = []
+    with torch.no_grad():
+        for frame, ft in zip(image, torch.linspace(0, 1, steps=t)):
+            tyx = F.pad(norm, pad=(1, 0), value=float(ft))
+            shifts = evaluate_deformation_field(field, tyx)
+            out.append(tp.sample_image_2d(frame, pixel_grid + shifts, interpolation="bicubic"))
+    return torch.stack(out, dim=0)
+
+
 def correct_motion_fast(image, deformation_grid, device=None):
     """correct_motion.py:430-498 -- Fourier phase-ramp shift by -field (used as pixels).
     Q1: negates the caller's grid IN PLACE (cm.py:473-474)."""

@@ -953,3 +953,62 @@ def test_local_motion_argument_errors(mc, dev):
         mc.estimate_local_motion(st, 1.0, (32, 32), (4, 1, 1), grid_type="linear", n_iterations=1)
     with pytest.raises(ValueError, match="Unsupported optimizer"):
         mc.estimate_local_motion(st, 1.0, (32, 32), (4, 1, 1), optimizer_type="adagrad", n_iterations=1)
+
+
+# ------------------------------------------------------------------ correct_motion_two_grids / _slow
+
+
+class _FakeSplineGrid:
+    """Stands for a grid object of the reference's spline dependency: `.data` + class name."""
+
+    def __init__(self, data):
+        self.data = data
+
+
+class CubicBSplineGrid3d(_FakeSplineGrid):
+    pass
+
+
+def _coord_knife(coords, h, w, eps=2e-3):
+    near = lambda v, n: (v.abs() < eps) | ((v - (n - 1)).abs() < eps)
+    return near(coords[..., 0], h) | near(coords[..., 1], w)
+
+
+def test_correct_motion_two_grids_matches_oracle(mc, dev):
+    g = torch.Generator().manual_seed(41)
+    img = torch.randn(4, 72, 88, generator=g)
+    new = torch.randn(2, 4, 2, 3, generator=g) * 2.0
+    base = torch.randn(2, 3, 3, 2, generator=g) * 1.5  # other resolution, B-spline basis
+    got = mc.correct_motion_two_grids(img.to(dev), new.to(dev), CubicBSplineGrid3d(base.to(dev)), 1.3,
+                                      grad=False)
+    ref = oracle.correct_motion_two_grids(img, new, base, 1.3, "catmull_rom", "bspline")
+    grid = tp.coordinate_grid((72, 88))
+    knife = torch.zeros(4, 72, 88, dtype=torch.bool)
+    for i, ft in enumerate(torch.linspace(0, 1, steps=4)):
+        lat = (oracle.evaluate_deformation_field_at_t(new, ft, (20, 30), "catmull_rom")
+               + oracle.evaluate_deformation_field_at_t(base, ft, (20, 30), "bspline"))
+        knife[i] = _coord_knife(grid + oracle.get_pixel_shifts(img[i], 1.3, lat, grid), 72, 88)
+    assert_frames_close(got, ref, knife, max_excluded=0.05)
+    with pytest.raises(NotImplementedError, match="grad=True"):
+        mc.correct_motion_two_grids(img.to(dev), new.to(dev).requires_grad_(True), base.to(dev), 1.3)
+    # same two tensors, default grad=True but nothing requires gradients: allowed
+    again = mc.correct_motion_two_grids(img.to(dev), new.to(dev), CubicBSplineGrid3d(base.to(dev)), 1.3)
+    assert torch.equal(again, got)
+
+
+def test_correct_motion_slow_matches_oracle(mc, dev):
+    """Per-pixel spline evaluation, shifts in PIXELS (correct_motion.py:302-427)."""
+    g = torch.Generator().manual_seed(43)
+    img = torch.randn(3, 64, 80, generator=g)
+    field = torch.randn(2, 3, 3, 2, generator=g) * 2.5
+    got = mc.correct_motion_slow(img.to(dev), field.to(dev))
+    ref = oracle.correct_motion_slow(img, field)
+    grid = tp.coordinate_grid((64, 80))
+    norm = grid / torch.tensor([63.0, 79.0])
+    knife = torch.zeros(3, 64, 80, dtype=torch.bool)
+    for i, ft in enumerate(torch.linspace(0, 1, steps=3)):
+        tyx = torch.nn.functional.pad(norm, (1, 0), value=float(ft))
+        knife[i] = _coord_knife(grid + oracle.evaluate_deformation_field(field, tyx), 64, 80)
+    assert_frames_close(got, ref, knife, max_excluded=0.05)
+    with pytest.raises(NotImplementedError):
+        mc.correct_motion_slow(img.to(dev), field.to(dev), grad=True)

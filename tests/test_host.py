@@ -335,3 +335,26 @@ def test_wave_fft_index_algebra_on_the_host(tmp_path, src):
                     os.path.join(root, "tests", src), "-o", str(exe), "-lm"], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
     assert out.strip().endswith("OK"), out
+
+
+def test_every_name_the_reference_exports_is_exported_here():
+    """src/torch_motion_correction/__init__.py:31-43 (__all__ of the reference)."""
+    import torch_motion_correction_amd as mc
+
+    reference_all = ["estimate_local_motion", "correct_motion", "correct_motion_two_grids", "correct_motion_fast",
+                     "correct_motion_slow", "get_pixel_shifts", "evaluate_deformation_field",
+                     "estimate_global_motion", "estimate_motion_cross_correlation_patches",
+                     "write_deformation_field_to_csv", "read_deformation_field_from_csv"]
+    for name in reference_all:
+        assert name in mc.__all__ and callable(getattr(mc, name)), name
+    import inspect
+
+    sig = inspect.signature(mc.estimate_local_motion)
+    assert list(sig.parameters) == ["image", "pixel_spacing", "patch_shape", "deformation_field_resolution",
+                                    "initial_deformation_field", "device", "n_iterations", "b_factor",
+                                    "frequency_range", "optimizer_type", "grid_type", "loss_type",
+                                    "optimizer_kwargs", "return_trajectory", "trajectory_kwargs"]  # :28-44
+    assert sig.parameters["n_iterations"].default == 100 and sig.parameters["loss_type"].default == "mse"
+    assert list(inspect.signature(mc.correct_motion_two_grids).parameters) == [
+        "image", "new_deformation_grid", "base_deformation_grid", "pixel_spacing", "grad", "device"]
+    assert list(inspect.signature(mc.correct_motion_slow).parameters) == ["image", "deformation_grid", "grad", "device"]

@@ -7,6 +7,8 @@ from .api import (  # noqa: F401
     condition_movie,
     correct_motion,
     correct_motion_fast,
+    correct_motion_slow,
+    correct_motion_two_grids,
     dose_weighted_sum,
     estimate_global_motion,
     estimate_local_motion,
@@ -27,6 +29,8 @@ from .pipeline import MoviePipeline, MovieResult, motion_correct_movies  # noqa:
 __all__ = [
     "correct_motion",
     "correct_motion_fast",
+    "correct_motion_slow",
+    "correct_motion_two_grids",
     "get_pixel_shifts",
     "evaluate_deformation_field",
     "estimate_global_motion",

@@ -194,6 +194,74 @@ def correct_motion(image, deformation_grid, pixel_spacing, grad=False, grid_type
     return frames.to(out_dev)
 
 
+def _grid_data_and_type(grid, default="catmull_rom"):
+    """A (c,nt,nh,nw) tensor, or a spline-grid object of the reference's dependency
+    (torch_cubic_spline_grids: `.data` holds the control points, the class name the basis)."""
+    if isinstance(grid, torch.Tensor):
+        return grid, default
+    data = getattr(grid, "data", None)
+    if not isinstance(data, torch.Tensor):
+        raise TypeError("expected a (2, nt, nh, nw) tensor or a cubic spline grid object with a .data tensor")
+    return data, ("bspline" if "bspline" in type(grid).__name__.lower() else "catmull_rom")
+
+
+def _wants_grad(grid) -> bool:
+    if isinstance(grid, torch.Tensor):
+        return grid.requires_grad
+    params = getattr(grid, "parameters", None)
+    return any(p.requires_grad for p in params()) if callable(params) else False
+
+
+def correct_motion_two_grids(image, new_deformation_grid, base_deformation_grid, pixel_spacing, grad=True,
+                             device=None):
+    """correct_motion.py:188-299 -- the frames resampled through the SUM of two spline grids
+    (an optimisable one and a frozen base), each evaluated on the (10 gh, 10 gw) lattice of the
+    new grid.  The grids are (2,nt,nh,nw) tensors (Catmull-Rom) or grid objects of the reference's
+    spline package; they may differ in resolution and basis.  Forward only: with ``grad=True`` (the
+    reference's default) a grid that requires gradients is refused instead of silently detached."""
+    if grad and _wants_grad(new_deformation_grid):
+        raise NotImplementedError("grad=True: gradients through the HIP resampling are not available "
+                                  "(pass grad=False or a detached grid)")
+    out_dev = _out_device(image, device)
+    dev = require_gpu(out_dev)
+    img = _stage(image, dev)
+    new, new_type = _grid_data_and_type(new_deformation_grid)
+    base, base_type = _grid_data_and_type(base_deformation_grid)
+    t = img.shape[0]
+    _, _, gh, gw = new.shape
+    lin = lambda n: torch.linspace(0, 1, steps=n)
+    lat = (engine.spline_lattice(_stage(new, dev), lin(t), lin(10 * gh), lin(10 * gw), new_type)
+           + engine.spline_lattice(_stage(base, dev), lin(t), lin(10 * gh), lin(10 * gw), base_type))
+    frames, _ = engine.warp(img, lat.permute(1, 0, 2, 3).contiguous(), float(pixel_spacing),
+                            want_frames=True, want_sum=False)
+    return frames.to(out_dev)
+
+
+def correct_motion_slow(image, deformation_grid, grad=False, device=None):
+    """correct_motion.py:302-427 -- the (2,nt,nh,nw) field evaluated (Catmull-Rom) at EVERY pixel
+    (t_i, y/(h-1), x/(w-1)) and used as PIXEL shifts (no pixel spacing), then bicubic resampling.
+    One frame at a time: the per-pixel shifts are a tensor-product spline lattice of the frame's
+    own size, which the general warp kernel consumes directly (its bicubic lattice upsample is the
+    identity at the lattice nodes up to 1e-4 of the shift difference between adjacent pixels)."""
+    if grad:
+        raise NotImplementedError("grad=True is not supported by the HIP path (forward only)")
+    out_dev = _out_device(image, device)
+    dev = require_gpu(out_dev)
+    img = _stage(image, dev)
+    field = _stage(deformation_grid, dev)
+    t, h, w = img.shape
+    times = torch.linspace(0, 1, steps=t)
+    uy = torch.arange(h, dtype=torch.float32) / float(h - 1)
+    ux = torch.arange(w, dtype=torch.float32) / float(w - 1)
+    out = torch.empty_like(img)
+    for f in range(t):
+        lat = engine.spline_lattice(field, times[f:f + 1], uy, ux, "catmull_rom")  # (2, 1, h, w)
+        frames, _ = engine.warp(img[f:f + 1], lat.permute(1, 0, 2, 3).contiguous(), 1.0,
+                                want_frames=True, want_sum=False)
+        out[f] = frames[0]
+    return out.to(out_dev)
+
+
 def motion_correct_sum(image, deformation_grid, pixel_spacing, grid_type="catmull_rom", device=None,
                        return_frames=False, dose_per_frame=None, pre_exposure=0.0, voltage=300.0):
     """Fused correct_motion + the caller-side ``torch.sum(movie, dim=0)`` of the
