@@ -1012,3 +1012,26 @@ def test_correct_motion_slow_matches_oracle(mc, dev):
     assert_frames_close(got, ref, knife, max_excluded=0.05)
     with pytest.raises(NotImplementedError):
         mc.correct_motion_slow(img.to(dev), field.to(dev), grad=True)
+
+
+def test_local_motion_1024_patches_take_the_wave_engine(dev):
+    """p = 1024 patches run the wavefront-per-row / per-column transforms (xc_rows_fwd_wave512,
+    xc_cols_fwd_wave1024); loss and gradient against the oracle's autograd on 2 x 2 patches."""
+    from torch_motion_correction_amd import local_motion
+
+    st, _, _ = drift_stack(3, 2048, 2048, seed=77)
+    res, patch = (3, 2, 2), (1024, 1024)
+    g = torch.Generator().manual_seed(5)
+    new = (torch.randn(2, *res, generator=g) * 1.0).requires_grad_(True)
+    init = torch.zeros(2, *res)
+    oprob = oracle.LocalMotionProblem(st, 1.0, patch)
+    total = oprob.batch_loss(new, init, "catmull_rom", list(range(oprob.npatch)), "mse")
+    total.backward()
+    prob = local_motion.LocalMotionProblem(st.to(dev), 1.0, patch, res, "catmull_rom")
+    assert prob.npatch == oprob.npatch == 4
+    wb = torch.full((4,), 0.25, dtype=torch.float64, device=dev)
+    nd = new.detach().to(dev).requires_grad_(True)
+    loss = local_motion._Loss.apply(prob.shifts_px(nd, init.to(dev)), prob, wb, "mse")
+    loss.backward()
+    assert abs(loss.item() - total.item()) <= 2e-4 * abs(total.item())
+    assert float((nd.grad.cpu() - new.grad).abs().max() / new.grad.abs().max()) <= 2e-4
