@@ -110,8 +110,12 @@ def main():
 
     def run_steps(n, record):
         last = None
-        for res in pipe.iterate([stack] * n, timed_warp if record else None):
-            last = res  # earlier results are dropped: their memory is reused by the next step
+        engine.RIGID_KERNEL_HOOK = timed_warp if record else None  # events around warp_rigid_dma alone
+        try:
+            for res in pipe.iterate([stack] * n):
+                last = res  # earlier results are dropped: their memory is reused by the next step
+        finally:
+            engine.RIGID_KERNEL_HOOK = None
         return last
 
     def barrier():
@@ -136,12 +140,20 @@ def main():
     if not args.no_overlap:
         lat = engine.frame_lattices(out.field.contiguous(), t, "catmull_rom")
         ev = []
-        for _ in range(3):
+
+        def solo_hook(fn):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            engine.warp(stack, lat, 1.0, want_frames=True, want_sum=True, rigid=True)
+            fn()
             e1.record()
             ev.append((e0, e1))
+
+        engine.RIGID_KERNEL_HOOK = solo_hook
+        try:
+            for _ in range(3):
+                engine.warp(stack, lat, 1.0, want_frames=True, want_sum=True, rigid=True)
+        finally:
+            engine.RIGID_KERNEL_HOOK = None
         torch.cuda.synchronize()
         solo_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
     shifts = (out.field[:, :, 0, 0].transpose(0, 1) / 1.0).cpu()

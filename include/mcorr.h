@@ -244,6 +244,11 @@ int mc_warp_frames(const float* frames, int nframes, int h, int w, const float* 
 int mc_warp_rigid_scratch_bytes(int nframes, int h, int w, int64_t* bytes /*host*/);
 int mc_warp_rigid(const float* frames, int nframes, int h, int w, const float* shifts_px,
                   float* scratch, float* out_frames, float* out_sum, void* stream);
+/* The same in two steps, for callers that want to time or schedule the resampling kernel on its
+ * own: phase 1 fills the per-frame weight tables in `scratch`, phase 2 (same arguments) resamples;
+ * phase 0 = mc_warp_rigid. */
+int mc_warp_rigid_phase(const float* frames, int nframes, int h, int w, const float* shifts_px,
+                        float* scratch, float* out_frames, float* out_sum, int phase, void* stream);
 
 /* get_pixel_shifts (correct_motion.py:132-185) for one (2,GH,GW) lattice: out (h,w,2)
  * shifts in px.  scratch: mc_warp_scratch_bytes(1,h,w,GH,GW). */

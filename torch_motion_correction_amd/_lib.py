@@ -66,6 +66,7 @@ SIGNATURES = {
     "mc_warp_frames": [vp, i32, i32, i32, vp, i32, i32, f32, vp, vp, vp, vp],
     "mc_warp_rigid_scratch_bytes": [i32, i32, i32, C.POINTER(C.c_int64)],
     "mc_warp_rigid": [vp, i32, i32, i32, vp, vp, vp, vp, vp],
+    "mc_warp_rigid_phase": [vp, i32, i32, i32, vp, vp, vp, vp, i32, vp],
     "mc_pixel_shifts": [vp, i32, i32, i32, i32, f32, vp, vp, vp],
     "mc_fourier_shift_cols_inverse": [vp, vp, vp, vp, vp, f32, i32, GP, vp],
     "mc_xc_rows_inverse_store": [vp, vp, vp, i64, vp, i32, GP, vp],

@@ -1302,24 +1302,32 @@ int mc_pixel_shifts(const float* lattice, int GH, int GW, int h, int w, float pi
   return mc_check_launch();
 }
 
+int mc_warp_rigid(const float* frames, int nframes, int h, int w, const float* shifts_px,
+                  float* scratch, float* out_frames, float* out_sum, void* stream);
+
 int mc_warp_rigid_scratch_bytes(int nframes, int h, int w, int64_t* bytes) {
   if (!bytes || nframes < 1 || h < 2 || w < 2) return MC_ERR_ARG;
   *bytes = ((int64_t)nframes * 5 * (h + w) + 2 * (int64_t)nframes + 8) * 4;
   return MC_OK;
 }
 
-int mc_warp_rigid(const float* frames, int nframes, int h, int w, const float* shifts_px,
-                  float* scratch, float* out_frames, float* out_sum, void* stream) {
+// phase 0: weight tables + resampling (mc_warp_rigid); 1: tables only; 2: resampling only, the
+// tables of an earlier phase-1 call with the same arguments are in `scratch`
+int mc_warp_rigid_phase(const float* frames, int nframes, int h, int w, const float* shifts_px,
+                        float* scratch, float* out_frames, float* out_sum, int phase, void* stream) {
   if (!frames || !shifts_px || !scratch || (!out_frames && !out_sum)) return MC_ERR_ARG;
-  if (nframes < 1 || h < 2 || w < 2 || (((uintptr_t)scratch) & 15)) return MC_ERR_ARG;
+  if (nframes < 1 || h < 2 || w < 2 || (((uintptr_t)scratch) & 15) || phase < 0 || phase > 2) return MC_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   float* Wy = scratch;
   float* Wx = Wy + (int64_t)nframes * 5 * h;
   int* S = reinterpret_cast<int*>(Wx + (int64_t)nframes * 5 * w);
   const int n = h > w ? h : w;
   dim3 tg((n + 255) / 256, nframes, 2);
-  hipLaunchKernelGGL(rigid_base, dim3(nframes, 2), dim3(256), 0, s, shifts_px, nframes, h, w, S);
-  hipLaunchKernelGGL(rigid_weights, tg, dim3(256), 0, s, shifts_px, nframes, h, w, S, Wy, Wx);
+  if (phase != 2) {
+    hipLaunchKernelGGL(rigid_base, dim3(nframes, 2), dim3(256), 0, s, shifts_px, nframes, h, w, S);
+    hipLaunchKernelGGL(rigid_weights, tg, dim3(256), 0, s, shifts_px, nframes, h, w, S, Wy, Wx);
+    if (phase == 1) return mc_check_launch();
+  }
   RigidArgs a;
   a.frames = frames; a.nframes = nframes; a.h = h; a.w = w; a.S = S; a.Wy = Wy; a.Wx = Wx;
   a.out_frames = out_frames; a.out_sum = out_sum;
@@ -1363,6 +1371,11 @@ int mc_warp_rigid(const float* frames, int nframes, int h, int w, const float* s
   else if (out_frames) hipLaunchKernelGGL((warp_rigid<true, false>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((warp_rigid<false, true>), grid, block, 0, s, a);
   return mc_check_launch();
+}
+
+int mc_warp_rigid(const float* frames, int nframes, int h, int w, const float* shifts_px,
+                  float* scratch, float* out_frames, float* out_sum, void* stream) {
+  return mc_warp_rigid_phase(frames, nframes, h, w, shifts_px, scratch, out_frames, out_sum, 0, stream);
 }
 
 }  // extern "C"

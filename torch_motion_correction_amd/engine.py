@@ -387,6 +387,9 @@ def frame_lattices(field, t, grid_type):
 # ------------------------------------------------------------------ a15/a17/a18: warp
 
 
+RIGID_KERNEL_HOOK = None  # callable(fn) -> calls fn(); set by bench.py to time warp_rigid_dma alone
+
+
 def warp(img, lattices, pixel_spacing, want_frames=True, want_sum=False, rigid=False):
     """Resample every frame through its lattice; returns (frames or None, sum or None).
     rigid=True: the lattices come from a (2,nt,1,1) field, i.e. one shift per frame ->
@@ -402,8 +405,14 @@ def warp(img, lattices, pixel_spacing, want_frames=True, want_sum=False, rigid=F
         shifts_px = (lattices[:, :, 0, 0] / pixel_spacing).contiguous()  # shifts_angstroms / ps
         check(lib.mc_warp_rigid_scratch_bytes(t, h, w, C.byref(nbytes)), "mc_warp_rigid_scratch_bytes")
         scratch = torch.empty((nbytes.value + 3) // 4, dtype=torch.float32, device=dev)
-        check(lib.mc_warp_rigid(ptr(img), t, h, w, ptr(shifts_px), ptr(scratch), ptr(frames),
-                                ptr(total), stream_ptr(dev)), "mc_warp_rigid")
+        if RIGID_KERNEL_HOOK is None:
+            check(lib.mc_warp_rigid(ptr(img), t, h, w, ptr(shifts_px), ptr(scratch), ptr(frames),
+                                    ptr(total), stream_ptr(dev)), "mc_warp_rigid")
+        else:  # instrumentation: the hook brackets the resampling kernel alone (bench.py)
+            args = (ptr(img), t, h, w, ptr(shifts_px), ptr(scratch), ptr(frames), ptr(total))
+            check(lib.mc_warp_rigid_phase(*args, 1, stream_ptr(dev)), "mc_warp_rigid_phase")
+            RIGID_KERNEL_HOOK(lambda: check(lib.mc_warp_rigid_phase(*args, 2, stream_ptr(dev)),
+                                            "mc_warp_rigid_phase"))
         return frames, total
     check(lib.mc_warp_scratch_bytes(t, h, w, GH, GW, C.byref(nbytes)), "mc_warp_scratch_bytes")
     scratch = torch.empty((nbytes.value + 3) // 4, dtype=torch.float32, device=dev)
