@@ -969,6 +969,60 @@ class CubicBSplineGrid3d(_FakeSplineGrid):
     pass
 
 
+class CubicCatmullRomGrid3d(torch.nn.Module):
+    """Module form, as the reference's tests build it: `.data` is a Parameter."""
+
+    def __init__(self, data):
+        super().__init__()
+        self._data = torch.nn.Parameter(data)
+
+    @property
+    def data(self):
+        return self._data
+
+
+def test_reference_suite_two_grids_and_slow(mc, dev):
+    """tests/test_correct_motion.py:202-253 (slow) and :304-553 (two grids) of the reference, on its
+    fixtures: shapes, devices, finiteness, zero-field identity within atol 0.1, detached output for
+    grad=False, attached output for grad=True."""
+    img = blob_stack(False)
+    t = img.shape[0]
+    field = ramp_field(t, 2)
+    new = CubicCatmullRomGrid3d(field.clone().to(dev))
+    zero = CubicCatmullRomGrid3d(torch.zeros(2, t, 2, 2, device=dev))
+    out = mc.correct_motion_two_grids(image=img, new_deformation_grid=new, base_deformation_grid=zero,
+                                      pixel_spacing=1.0, device=dev)
+    assert out.shape == img.shape and out.device.type == "cuda" and torch.isfinite(out).all()
+    assert out.requires_grad  # test_gradient_preservation, first half
+    det = mc.correct_motion_two_grids(img, new, zero, 1.0, grad=False, device=dev)
+    assert not det.requires_grad and torch.equal(det, out.detach())
+    bs = mc.correct_motion_two_grids(img, CubicBSplineGrid3d(field.clone().to(dev)),
+                                     CubicBSplineGrid3d(torch.zeros(2, t, 2, 2, device=dev)), 1.0, device=dev)
+    assert bs.shape == img.shape
+    ident = mc.correct_motion_two_grids(img, zero, zero, 1.0, device=dev)
+    assert torch.allclose(ident.detach().cpu(), img, atol=0.1)
+    slow = mc.correct_motion_slow(image=img, deformation_grid=field, device=dev)
+    assert slow.shape == img.shape and slow.device.type == "cuda" and not slow.requires_grad
+    assert torch.allclose(mc.correct_motion_slow(img, torch.zeros(2, t, 2, 2), device=dev).cpu(), img, atol=0.1)
+
+
+def test_reference_suite_local_motion(mc, dev):
+    """tests/test_estimate_motion.py:197-304 of the reference on its fixture (5 x 64 x 64 blob,
+    32-px patches, (t, 2, 2) grid, 2 iterations): shapes for every optimiser / basis / loss it
+    exercises, trajectory returned, optimiser kwargs accepted."""
+    img = blob_stack(True)
+    t = img.shape[0]
+    kw = dict(pixel_spacing=1.0, patch_shape=(32, 32), deformation_field_resolution=(t, 2, 2),
+              initial_deformation_field=None, device=dev, n_iterations=2)
+    for extra in ({"optimizer_type": "adam"}, {"optimizer_type": "sgd"}, {"grid_type": "bspline"},
+                  {"loss_type": "ncc"}, {"optimizer_type": "adam", "optimizer_kwargs": {"lr": 0.001}},
+                  {"initial_deformation_field": torch.zeros(2, t, 2, 2)}):
+        out = mc.estimate_local_motion(image=img, **{**kw, **extra})
+        assert out.shape == (2, t, 2, 2) and isinstance(out, torch.Tensor) and torch.isfinite(out).all()
+    out, traj = mc.estimate_local_motion(image=img, **kw, return_trajectory=True)
+    assert out.shape == (2, t, 2, 2) and traj is not None and len(traj.checkpoints) == 2
+
+
 def _coord_knife(coords, h, w, eps=2e-3):
     near = lambda v, n: (v.abs() < eps) | ((v - (n - 1)).abs() < eps)
     return near(coords[..., 0], h) | near(coords[..., 1], w)
@@ -989,8 +1043,13 @@ def test_correct_motion_two_grids_matches_oracle(mc, dev):
                + oracle.evaluate_deformation_field_at_t(base, ft, (20, 30), "bspline"))
         knife[i] = _coord_knife(grid + oracle.get_pixel_shifts(img[i], 1.3, lat, grid), 72, 88)
     assert_frames_close(got, ref, knife, max_excluded=0.05)
-    with pytest.raises(NotImplementedError, match="grad=True"):
-        mc.correct_motion_two_grids(img.to(dev), new.to(dev).requires_grad_(True), base.to(dev), 1.3)
+    # grad=True with a grid that requires gradients: forward as in the reference (attached result),
+    # backward refused loudly
+    att = mc.correct_motion_two_grids(img.to(dev), new.to(dev).requires_grad_(True), base.to(dev), 1.3)
+    assert att.requires_grad and torch.equal(att.detach(), mc.correct_motion_two_grids(
+        img.to(dev), new.to(dev), base.to(dev), 1.3, grad=False))
+    with pytest.raises(NotImplementedError, match="forward only"):
+        att.sum().backward()
     # same two tensors, default grad=True but nothing requires gradients: allowed
     again = mc.correct_motion_two_grids(img.to(dev), new.to(dev), CubicBSplineGrid3d(base.to(dev)), 1.3)
     assert torch.equal(again, got)

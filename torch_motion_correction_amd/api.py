@@ -218,10 +218,8 @@ def correct_motion_two_grids(image, new_deformation_grid, base_deformation_grid,
     (an optimisable one and a frozen base), each evaluated on the (10 gh, 10 gw) lattice of the
     new grid.  The grids are (2,nt,nh,nw) tensors (Catmull-Rom) or grid objects of the reference's
     spline package; they may differ in resolution and basis.  Forward only: with ``grad=True`` (the
-    reference's default) a grid that requires gradients is refused instead of silently detached."""
-    if grad and _wants_grad(new_deformation_grid):
-        raise NotImplementedError("grad=True: gradients through the HIP resampling are not available "
-                                  "(pass grad=False or a detached grid)")
+    reference's default) and a grid that requires gradients the result is attached to that grid, as
+    in the reference, but calling ``backward`` through it raises NotImplementedError."""
     out_dev = _out_device(image, device)
     dev = require_gpu(out_dev)
     img = _stage(image, dev)
@@ -234,7 +232,27 @@ def correct_motion_two_grids(image, new_deformation_grid, base_deformation_grid,
            + engine.spline_lattice(_stage(base, dev), lin(t), lin(10 * gh), lin(10 * gw), base_type))
     frames, _ = engine.warp(img, lat.permute(1, 0, 2, 3).contiguous(), float(pixel_spacing),
                             want_frames=True, want_sum=False)
-    return frames.to(out_dev)
+    frames = frames.to(out_dev)
+    if grad and _wants_grad(new_deformation_grid):
+        # the reference returns frames attached to the new grid's graph; the forward here is the
+        # same, the backward is refused where it would be needed
+        params = ([new_deformation_grid] if isinstance(new_deformation_grid, torch.Tensor)
+                  else [p for p in new_deformation_grid.parameters() if p.requires_grad])
+        frames = _ForwardOnly.apply(frames, *params)
+    return frames
+
+
+class _ForwardOnly(torch.autograd.Function):
+    """Marks a HIP result as depending on `params`; differentiating through it fails loudly."""
+
+    @staticmethod
+    def forward(ctx, frames, *params):
+        return frames.view_as(frames)
+
+    @staticmethod
+    def backward(ctx, gout):
+        raise NotImplementedError("gradients through the HIP resampling kernels are not available "
+                                  "(forward only); use grad=False")
 
 
 def correct_motion_slow(image, deformation_grid, grad=False, device=None):
