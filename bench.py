@@ -205,7 +205,19 @@ def main():
                 "estimate_ms": 1e3 * est, "correct_sum_ms": 1e3 * cor, "frames_per_s": t3 / (est + cor),
                 "sum_finite": bool(torch.isfinite(s3).all()),
             }
-            del st3, f3, s3
+            # the optimiser-based estimator on the same movie: 100 Adam iterations refining the
+            # patch field's lattice (estimate_local_motion; second call = plans and torch.optim warm)
+            lm = []
+            for _ in range(2):
+                torch.cuda.synchronize()
+                c0 = time.perf_counter()
+                fl = mc.estimate_local_motion(st3, 1.0, (1024, 1024), (t3, f3.shape[2], f3.shape[3]), f3,
+                                              n_iterations=100)
+                torch.cuda.synchronize()
+                lm.append(time.perf_counter() - c0)
+            secondary["local_motion_100_adam_iterations_ms"] = 1e3 * lm[-1]
+            secondary["local_motion_field_finite"] = bool(torch.isfinite(fl).all())
+            del st3, f3, s3, fl
         except Exception as e:  # never let the secondary workload break the headline line
             secondary = {"error": repr(e)}
 

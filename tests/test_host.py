@@ -358,3 +358,39 @@ def test_every_name_the_reference_exports_is_exported_here():
     assert list(inspect.signature(mc.correct_motion_two_grids).parameters) == [
         "image", "new_deformation_grid", "base_deformation_grid", "pixel_spacing", "grad", "device"]
     assert list(inspect.signature(mc.correct_motion_slow).parameters) == ["image", "deformation_grid", "grad", "device"]
+
+
+def test_three_operation_division_is_the_correctly_rounded_quotient():
+    """warp.hip grid_chain divides by the invariant d = 0.5 n - 0.5 as q = c r; e = fma(-q, d, c);
+    q' = fma(e, r, q).  Checked here against exact rational arithmetic (the reference divides)."""
+    from fractions import Fraction
+    import math
+
+    def rn32(fr):
+        if fr == 0:
+            return np.float32(0)
+        sgn = 1 if fr > 0 else -1
+        fr = abs(fr)
+        e = math.floor(math.log2(fr))
+        while Fraction(2) ** e > fr:
+            e -= 1
+        while Fraction(2) ** (e + 1) <= fr:
+            e += 1
+        scaled = fr / Fraction(2) ** e * (1 << 23)
+        fl = scaled.numerator // scaled.denominator
+        rem = scaled - fl
+        if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and fl % 2 == 1):
+            fl += 1
+        return np.float32(sgn * float(fl) * 2.0 ** (e - 23))
+
+    rng = np.random.default_rng(0)
+    for n in (64, 959, 4092, 4096, 5760, 8184, 11520):
+        d = np.float32(0.5) * np.float32(n) - np.float32(0.5)
+        r = np.float32(1.0) / d
+        a = (rng.random(300, dtype=np.float32) * np.float32(n + 40) - np.float32(20)).astype(np.float32)
+        a[:100] = np.round(a[:100]) + rng.choice([0, 1e-4, -1e-4, 0.5], 100).astype(np.float32)
+        for x in a:
+            q = np.float32(x * r)
+            e = rn32(Fraction(float(x)) - Fraction(float(q)) * Fraction(float(d)))
+            q1 = rn32(Fraction(float(q)) + Fraction(float(e)) * Fraction(float(r)))
+            assert q1 == rn32(Fraction(float(x)) / Fraction(float(d))), (n, x)

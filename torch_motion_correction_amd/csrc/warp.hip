@@ -35,8 +35,18 @@ __device__ __forceinline__ void cubic_coeffs(float t, float c[4]) {
 
 // grid_sample align_corners=True un-normalisation applied to an array coordinate that
 // went through array_to_grid_sample:  ((c / (0.5 n - 0.5) - 1) + 1) * ((n - 1) / 2)
+// The division by the loop-invariant d = 0.5 n - 0.5 is done as q = c r, e = fma(-q, d, c),
+// q' = fma(e, r, q) with r = RN(1/d): that IS the correctly rounded quotient (Markstein; the one
+// exception, a divisor whose significand is all ones, cannot occur for d with <= 15 significant
+// bits; checked against exact rational arithmetic for the frame sizes in use, tests/test_host.py)
+// at 3 instructions instead of the ~12 of a general IEEE division -- twice per pixel.
 __device__ __forceinline__ float grid_chain(float c, float n) {
-  const float g = c / (0.5f * n - 0.5f) - 1.f;
+  const float d = 0.5f * n - 0.5f;
+  const float r = 1.0f / d;
+  float q = c * r;
+  const float e = __builtin_fmaf(-q, d, c);
+  q = __builtin_fmaf(e, r, q);
+  const float g = q - 1.f;
   return (g + 1.f) * ((n - 1.f) / 2.f);
 }
 
