@@ -50,6 +50,13 @@ __device__ __forceinline__ float grid_chain(float c, float n) {
   return (g + 1.f) * ((n - 1.f) / 2.f);
 }
 
+// s / d for a loop-invariant divisor, same three-instruction correctly rounded form
+__device__ __forceinline__ float div_invariant(float s, float d) {
+  const float r = 1.0f / d;
+  const float q = s * r;
+  return __builtin_fmaf(__builtin_fmaf(-q, d, s), r, q);
+}
+
 __device__ __forceinline__ int reflect_index(int i, int size) {
   const int span = size - 1;
   if (span <= 0) return 0;
@@ -193,8 +200,8 @@ __device__ __forceinline__ void warp_row(const WarpArgs& a, const float* fr, int
     float sy = dot4(yc, ey[0][k], ey[1][k], ey[2][k], ey[3][k]);
     float sx = dot4(yc, ex[0][k], ex[1][k], ex[2][k], ex[3][k]);
     if (!UNIT_PS) {
-      sy = sy / a.pixel_spacing;
-      sx = sx / a.pixel_spacing;
+      sy = div_invariant(sy, a.pixel_spacing);
+      sx = div_invariant(sx, a.pixel_spacing);
     }
     const float cy = (float)y + sy, cx = (float)(x0 + k) + sx;
     inside[k] = (cy >= 0.f) && (cy <= fh - 1.f) && (cx >= 0.f) && (cx <= fw - 1.f);
@@ -972,8 +979,8 @@ __global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES, 2) void warp_field(FieldA
       float sx = dot4(ycc, Ec[chs + (int64_t)ytc.x * w], Ec[chs + (int64_t)ytc.y * w],
                       Ec[chs + (int64_t)ytc.z * w], Ec[chs + (int64_t)ytc.w * w]);
       if (!UNIT_PS) {
-        sy = sy / a.pixel_spacing;
-        sx = sx / a.pixel_spacing;
+        sy = div_invariant(sy, a.pixel_spacing);
+        sx = div_invariant(sx, a.pixel_spacing);
       }
       const float lim = 4.f * (fh + fw);
       const float dy = fminf(fmaxf(floorf(grid_chain((float)yc + sy, fh)) - (float)yc, -lim), lim);
@@ -1040,8 +1047,8 @@ __global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES, 2) void warp_field(FieldA
         float sy = dot4(yc4, ey[0][k], ey[1][k], ey[2][k], ey[3][k]);
         float sx = dot4(yc4, ex[0][k], ex[1][k], ex[2][k], ex[3][k]);
         if (!UNIT_PS) {
-          sy = sy / a.pixel_spacing;
-          sx = sx / a.pixel_spacing;
+          sy = div_invariant(sy, a.pixel_spacing);
+          sx = div_invariant(sx, a.pixel_spacing);
         }
         const float cy = (float)y + sy, cx = (float)x + sx;
         const bool inside = (cy >= 0.f) && (cy <= fh - 1.f) && (cx >= 0.f) && (cx <= fw - 1.f);
@@ -1118,8 +1125,8 @@ __global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES) void warp_field_slow(Fiel
       float sx = dot4(yc4, E[chs + (int64_t)yt4.x * w], E[chs + (int64_t)yt4.y * w],
                       E[chs + (int64_t)yt4.z * w], E[chs + (int64_t)yt4.w * w]);
       if (!UNIT_PS) {
-        sy = sy / a.pixel_spacing;
-        sx = sx / a.pixel_spacing;
+        sy = div_invariant(sy, a.pixel_spacing);
+        sx = div_invariant(sx, a.pixel_spacing);
       }
       const float cy = (float)y + sy, cx = (float)x + sx;
       const bool inside = (cy >= 0.f) && (cy <= fh - 1.f) && (cx >= 0.f) && (cx <= fw - 1.f);
