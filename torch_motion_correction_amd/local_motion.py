@@ -72,6 +72,9 @@ class LocalMotionProblem:
             raise ValueError("estimate_local_motion needs at least 2 frames (patch centres are normalised by t - 1)")
         if ph > h or pw > w:
             raise ValueError(f"Patch size {(ph, pw)} too large for image of shape {(t, h, w)}")
+        if t > 512:
+            raise NotImplementedError(f"{t} frames: the loss kernels keep the per-frame shifts of a patch in LDS "
+                                      "(mc_local_loss_sums: at most 512 frames)")
         self.t, self.h, self.w, self.ph, self.pw, self.dev = t, h, w, ph, pw, dev
         self.ps = float(pixel_spacing)
         self.res = tuple(int(r) for r in resolution)
