@@ -124,11 +124,16 @@ int mc_xc_provisional_mean(const float* x, int n, float* m0, void* stream);
  * coordinates, inside the mask support, wl/wu even) of every job are accumulated;
  * afterwards fix = {mean - m0, 1/std} and out3 = {mean, 1/std, std} (unbiased std over
  * all jobs jointly, utils.py:76-84).  acc: 128 doubles scratch (64 x {sum, sumsq}).  Feed `fix` to
- * mc_xc_cols_forward_fix, which finishes the normalisation by linearity. */
+ * mc_xc_cols_forward_fix, which finishes the normalisation by linearity.
+ * row_chord (NULL, or H x 2 ints per WINDOW row y: first and last 4-aligned column whose quad
+ * holds a non-zero mask value): samples outside a row's chord of the mask disk are not fetched
+ * (they are multiplied by the mask's exact zero) -- 21 % of the support box of a circular mask.
+ * The statistics box must lie inside the chords (the caller checks; plan.row_chords). */
 int mc_xc_rows_forward_stats(const float* src, const int64_t* job_off, int64_t row_stride,
                              const float* mask, const float* m0, void* T1, const void* tw_row,
                              int njobs, const mc_xc_geom* geom, int hl, int hu, int wl, int wu,
-                             double* acc, float* fix, float* out3, void* stream);
+                             double* acc, float* fix, float* out3, const int* row_chord,
+                             void* stream);
 
 /* K2.  Column FFT of T1, kept ky rows, times filt (or NULL) -> S[j][kx][kyi].
  * estimate_motion_xc.py:78,98 / :340-346. */

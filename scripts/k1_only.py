@@ -1,3 +1,4 @@
+import os
 """K1 (rows forward, 40 x 4096 x 4096) alone, a few launches: for rocprofv3 passes."""
 import sys, torch
 sys.path.insert(0, ".")
@@ -18,7 +19,8 @@ acc = torch.empty(128, dtype=torch.float64, device=dev); fix = torch.empty(2, de
 st = stream_ptr(dev)
 def k1():
     check(lib.mc_xc_rows_forward_stats(ptr(stack), ptr(off), w, ptr(pl.mask), ptr(m0), ptr(T1), ptr(pl.tw_row), t, gm,
-                                       hl, hu, wl, wu, ptr(acc), ptr(fix), ptr(out3), st), "k1")
+                                       hl, hu, wl, wu, ptr(acc), ptr(fix), ptr(out3),
+                                       ptr(pl.chord) if os.environ.get("MC_ROW_CHORDS", "1") != "0" else None, st), "k1")
 modes = [int(a) for a in sys.argv[1:]] or [0, 1]  # 0 = wave-per-row engine, 1 = workgroup-per-row
 for rep in range(2):
     for mode in modes:

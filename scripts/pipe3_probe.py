@@ -30,7 +30,7 @@ def stage1():  # K1 (+ provisional mean)
     fix = torch.empty(2, device=dev); out3 = torch.empty(3, device=dev)
     T1 = torch.empty((t, g.nkx, g.ny, 2), device=dev)
     check(lib.mc_xc_rows_forward_stats(ptr(stack), ptr(job_off), w, ptr(pl.mask), ptr(m0), ptr(T1), ptr(pl.tw_row), t, g,
-                                       hl, hu, wl, wu, ptr(acc), ptr(fix), ptr(out3), st), "k1")
+                                       hl, hu, wl, wu, ptr(acc), ptr(fix), ptr(out3), ptr(pl.chord), st), "k1")
     return T1, fix
 
 def stage2(T1, fix):  # K2 .. K5

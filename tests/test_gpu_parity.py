@@ -572,7 +572,8 @@ def test_wave_row_engine_matches_workgroup_engine(dev, h, fr):
             out3 = torch.empty(3, device=dev)
             check(lib.mc_xc_rows_forward_stats(ptr(img), ptr(off), w, ptr(pl.mask), ptr(m0), ptr(T1),
                                                ptr(pl.tw_row), t, gm, hl, hu, wl, wu, ptr(acc), ptr(fix),
-                                               ptr(out3), stream_ptr(dev)), "rows_forward_stats")
+                                               ptr(out3), ptr(pl.chord) if mode == 0 else None,
+                                               stream_ptr(dev)), "rows_forward_stats")
             plain = torch.zeros_like(T1)
             st = torch.tensor([11.0, 0.5], device=dev)
             check(lib.mc_xc_rows_forward(ptr(img), ptr(off), w, None, ptr(pl.mask), ptr(st), ptr(plain),

@@ -203,12 +203,12 @@ __device__ __forceinline__ void wf_pin(int& v, float dep) { asm volatile("" : "+
 // Statistics: box.wl / box.wu are multiples of 256 (host checks), so a chunk is inside
 // the box or outside it as a whole.
 template <int N1LO, int N1HI, bool CLAMP_ALL>
-__device__ __forceinline__ void wf_load_px(const float* __restrict__ row, int t, const XcGeom& g,
+__device__ __forceinline__ void wf_load_px(const float* __restrict__ row, int t, int xlo, int xhi,
                                            float4 (&px)[16]) {
-  // Branch-free: a lane whose quad lies outside the support [x0, x1) reads the nearest quad
+  // Branch-free: a lane whose quad lies outside [xlo, xhi + 4) -- the support box, or with
+  // CLAMP_ALL and a chord table this row's own chord of the mask disk -- reads the nearest quad
   // inside it instead (a line its neighbours fetch anyway: no extra HBM traffic); the value
   // is later multiplied by the mask's exact zero.
-  const int xlo = g.x0 & ~3, xhi = ((g.x1 + 3) & ~3) - 4;
 #pragma unroll
   for (int n1 = N1LO; n1 < N1HI; ++n1) {
     const int x = 256 * n1 + 4 * t;
@@ -238,9 +238,10 @@ __device__ __forceinline__ void wf_row(float4 (&px)[16], float4 (&mk)[16],
                                        const float* __restrict__ next_mrow, int t, wf2* slab,
                                        const cfloat* twA, const cfloat* twB, const cfloat* twK,
                                        const XcGeom& g, int box_lo, int box_hi, float mean, float rstd,
-                                       float& st_s, float& st_q, wf2 (&X)[4][KEEP]) {
+                                       float& st_s, float& st_q, wf2 (&X)[4][KEEP], int xlo, int xhi,
+                                       int nxlo, int nxhi) {
   wf2 A0[16], A1[16];
-  if (PREFETCH < 1) wf_load_px<N1LO, N1HI, CLAMP_ALL>(row, t, g, px);
+  if (PREFETCH < 1) wf_load_px<N1LO, N1HI, CLAMP_ALL>(row, t, xlo, xhi, px);
   if (PREFETCH < 2) wf_load_mask<N1LO, N1HI>(mrow, t, mk);
   auto condition = [&](auto in_box) {
     constexpr bool INBOX = decltype(in_box)::value;
@@ -277,7 +278,7 @@ __device__ __forceinline__ void wf_row(float4 (&px)[16], float4 (&mk)[16],
     if (next_row) {  // issued once this row's samples have been consumed, not earlier
       int tp = t;
       wf_pin(tp, A1[N1HI - 1].y);
-      wf_load_px<N1LO, N1HI, CLAMP_ALL>(next_row, tp, g, px);
+      wf_load_px<N1LO, N1HI, CLAMP_ALL>(next_row, tp, nxlo, nxhi, px);
       if (PREFETCH >= 2) wf_load_mask<N1LO, N1HI>(next_mrow, tp, mk);
     }
   }
@@ -354,7 +355,8 @@ template <int KEEP, bool STATS, int N1LO, int N1HI, bool CLAMP_ALL, int WF_PREFE
 __global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
     const float* __restrict__ src, const int64_t* __restrict__ job_off, int64_t row_stride,
     const float* __restrict__ mask, const float* __restrict__ mean_rstd, cfloat* __restrict__ T1,
-    const cfloat* __restrict__ tw_row, XcGeom g, XcBox box, double* __restrict__ stats_acc) {
+    const cfloat* __restrict__ tw_row, XcGeom g, XcBox box, double* __restrict__ stats_acc,
+    const int2* __restrict__ chord) {
   __shared__ __attribute__((aligned(16))) cfloat slabs[4][WF_SLAB];
   __shared__ __attribute__((aligned(16))) cfloat tab[WF_TWA + WF_TWB + 256];
   const cfloat* twA = tab;
@@ -410,8 +412,14 @@ __global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
   auto row_of = [&](int i) { return r16 + (i >> 1) * 8 + 2 * wv + (i & 1); };  // i = 0..3
   const int nrows = g.ny - r16 >= 16 ? 4 : (g.ny - r16 >= 8 ? 2 : 0);  // ny % 8 == 0
   float4 px[16], mk[16];
-  if (WF_PREFETCH >= 1 && nrows > 0)
-    wf_load_px<N1LO, N1HI, CLAMP_ALL>(base + (int64_t)(g.y0 + row_of(0)) * row_stride, t, g, px);
+  // clamp bounds of a row's sample loads: the support box, or (CLAMP_ALL with a table) the row's
+  // own chord of the mask disk -- the corners of the box, 21 % of it, are then never fetched
+  const int bxlo = g.x0 & ~3, bxhi = ((g.x1 + 3) & ~3) - 4;
+  auto bounds = [&](int y) { return (CLAMP_ALL && chord) ? chord[y] : make_int2(bxlo, bxhi); };
+  if (WF_PREFETCH >= 1 && nrows > 0) {
+    const int2 c0 = bounds(g.y0 + row_of(0));
+    wf_load_px<N1LO, N1HI, CLAMP_ALL>(base + (int64_t)(g.y0 + row_of(0)) * row_stride, t, c0.x, c0.y, px);
+  }
   if (WF_PREFETCH >= 2 && nrows > 0)
     wf_load_mask<N1LO, N1HI>(mask + (int64_t)(g.y0 + row_of(0)) * g.W, t, mk);
   __syncthreads();
@@ -426,10 +434,11 @@ __global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
     const float* next_mrow = mask + (int64_t)yn * g.W;
     const bool in_box_row = STATS && y >= box.hl && y < box.hu;
     wf2 X[4][KEEP];
+    const int2 cb = bounds(y), cn = bounds(rr + 1 < nrows ? yn : y);
     wf_row<KEEP, STATS, N1LO, N1HI, CLAMP_ALL, WF_PREFETCH>(px, mk, row, mrow, next_row, next_mrow, t,
                                                             slab, twA, twB, twK, g, box.wl >> 8,
                                                             in_box_row ? (box.wu >> 8) : 0, mean, rstd,
-                                                            st_s, st_q, X);
+                                                            st_s, st_q, X, cb.x, cb.y, cn.x, cn.y);
     if (rr & 1) {
       int ts = t;
       wf_pin(ts, X[0][0].x);  // addresses: computed here, not carried across rows
@@ -1493,7 +1502,8 @@ int mc_xc_rows_lds_bytes(const mc_xc_geom* q) {
 static int rows_forward_impl(const float* src, const int64_t* job_off, int64_t row_stride,
                              const int* job_expo, const float* mask, const float* mean_rstd,
                              void* T1, const void* tw_row, int njobs, const mc_xc_geom* q,
-                             const XcBox* box, double* stats_acc, void* stream) {
+                             const XcBox* box, double* stats_acc, void* stream,
+                             const int* row_chord = nullptr) {
   XcGeom g;
   int rc = geom_from(q, &g, true, false);
   if (rc) return rc;
@@ -1509,10 +1519,12 @@ static int rows_forward_impl(const float* src, const int64_t* job_off, int64_t r
 #define MC_WAVE_LAUNCH(KEEP, ST, LO, HI, CL, PF)                                                  \
   hipLaunchKernelGGL((xc_rows_fwd_wave<KEEP, ST, LO, HI, CL, PF>), grid, dim3(256), 0,            \
                      (hipStream_t)stream, src, job_off, row_stride, mask, mean_rstd, (cfloat*)T1,   \
-                     (const cfloat*)tw_row, g, b, stats_acc)
+                     (const cfloat*)tw_row, g, b, stats_acc, (const int2*)row_chord)
 #define MC_WAVE_PICK(KEEP, ST)                                                              \
   do {                                                                                      \
-    if (g.x0 >= 256 && g.x0 <= 512 && g.x1 >= 3584 && g.x1 <= 3840)                         \
+    if (g.x0 >= 256 && g.x0 <= 512 && g.x1 >= 3584 && g.x1 <= 3840 && row_chord)            \
+      MC_WAVE_LAUNCH(KEEP, ST, 1, 15, true, WF_PREFETCH_DEFAULT); /* per-row chord clamp */  \
+    else if (g.x0 >= 256 && g.x0 <= 512 && g.x1 >= 3584 && g.x1 <= 3840)                    \
       MC_WAVE_LAUNCH(KEEP, ST, 1, 15, false, WF_PREFETCH_DEFAULT); /* square 4096 frames */ \
     else                                                                                    \
       MC_WAVE_LAUNCH(KEEP, ST, 0, 16, true, WF_PREFETCH_DEFAULT);                           \
@@ -1579,7 +1591,7 @@ int mc_xc_provisional_mean(const float* x, int n, float* m0, void* stream) {
 int mc_xc_rows_forward_stats(const float* src, const int64_t* job_off, int64_t row_stride,
                              const float* mask, const float* m0, void* T1, const void* tw_row,
                              int njobs, const mc_xc_geom* q, int hl, int hu, int wl, int wu,
-                             double* acc, float* fix, float* out3, void* stream) {
+                             double* acc, float* fix, float* out3, const int* row_chord, void* stream) {
   if (!m0 || !acc || !fix || !out3 || !q) return MC_ERR_ARG;
   if (hl < q->y0 || hu > q->y0 + q->ny || wl < q->x0 || wu > q->x1 || (wl & 1) || (wu & 1) ||
       hl >= hu || wl >= wu)
@@ -1588,7 +1600,7 @@ int mc_xc_rows_forward_stats(const float* src, const int64_t* job_off, int64_t r
   if (e != hipSuccess) return (int)e;
   XcBox box{hl, hu, wl, wu};
   int rc = rows_forward_impl(src, job_off, row_stride, nullptr, mask, m0, T1, tw_row, njobs, q, &box,
-                             acc, stream);
+                             acc, stream, row_chord);
   if (rc) return rc;
   const double count = (double)njobs * (hu - hl) * (wu - wl);
   hipLaunchKernelGGL(xc_stats_finalize, dim3(1), dim3(1), 0, (hipStream_t)stream, acc, count, m0, fix,

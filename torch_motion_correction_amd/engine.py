@@ -243,10 +243,36 @@ def _global_spectra(img, pl):
     S = torch.empty((t, g.nkx, g.nky, 2), dtype=torch.float32, device=dev)
     check(lib.mc_xc_rows_forward_stats(ptr(img), ptr(job_off), w, ptr(pl.mask), ptr(m0), ptr(T1),
                                        ptr(pl.tw_row), t, g, hl, hu, wl, wu, ptr(acc), ptr(fix),
-                                       ptr(out3), st), "mc_xc_rows_forward_stats")
+                                       ptr(out3), ptr(_box_chords(pl, hl, hu, wl, wu)), st),
+          "mc_xc_rows_forward_stats")
     check(lib.mc_xc_cols_forward_fix(ptr(T1), ptr(pl.filt), ptr(S), ptr(pl.tw_col), t, g, ptr(fix),
                                      ptr(mhat), st), "mc_xc_cols_forward_fix")
     return S
+
+
+def _os_env_flag(name, default):
+    import os
+
+    v = os.environ.get(name)
+    return default if v is None else v not in ("0", "false", "no")
+
+
+def _box_chords(pl, hl, hu, wl, wu):
+    """The plan's per-row chord table if the statistics box lies inside the chords (it does for
+    the reference's circular mask: the box corner is at 0.35 n from the centre, the soft edge ends
+    at 0.375 n), else None: K1 then clamps to the support box only."""
+    if pl.chord is None or not USE_ROW_CHORDS:
+        return None
+    key = ("chord_ok", id(pl), hl, hu, wl, wu)
+
+    def build():
+        c = pl.chord[hl:hu]
+        return bool((c[:, 0] <= wl).all()) and bool((c[:, 1] + 4 >= wu).all())
+
+    return pl.chord if _cached(key, build) else None
+
+
+USE_ROW_CHORDS = _os_env_flag("MC_ROW_CHORDS", True)
 
 
 def global_shifts(img, reference_frame, pixel_spacing, b_factor, frequency_range):

@@ -161,6 +161,21 @@ class XcPlan:
     low: float
     high: float
     mhat: object = None  # pruned spectrum of the mask (engine.mask_spectrum), built lazily
+    chord: object = None  # (H, 2) int32: per-row [first, last] 4-aligned column with a non-zero mask quad
+
+
+def row_chords(mask: torch.Tensor) -> torch.Tensor:
+    """Per window row, the first and the last 4-aligned column whose quad holds a non-zero mask
+    value (rows without any: the middle quad).  K1 clamps its sample loads to that range."""
+    h, w = mask.shape
+    nz = (mask != 0).reshape(h, w // 4, 4).any(dim=2)  # (h, w/4) quads
+    any_ = nz.any(dim=1)
+    first = torch.argmax(nz.to(torch.int32), dim=1)
+    last = (w // 4 - 1) - torch.argmax(nz.flip(1).to(torch.int32), dim=1)
+    mid = torch.full_like(first, (w // 8))
+    first = torch.where(any_, first, mid)
+    last = torch.where(any_, last, mid)
+    return (torch.stack([first, last], dim=1) * 4).to(torch.int32).contiguous()
 
 
 _PLANS: dict = {}
@@ -202,6 +217,8 @@ def get_xc_plan(h: int, w: int, pixel_spacing: float, b_factor: float, frequency
     check(lib.mc_xc_filter(ptr(filt), geom, low, high, float(b_factor), float(pixel_spacing),
                            stream_ptr(device)), "mc_xc_filter")
     plan = XcPlan(geom, mask, filt, get_twiddles(w, device), get_twiddles(h, device), low, high)
+    if w % 4 == 0:
+        plan.chord = row_chords(mask)
     _PLANS[key] = plan
     return plan
 
