@@ -100,7 +100,8 @@ int mc_dose_accumulate(const void* S, int nframes, int frame0, int total_frames,
 int mc_xc_rows_forward_dual(const float* src, const int64_t* job_off, int64_t row_stride,
                             const int* expo_a, const int* expo_b, const float* mask,
                             const float* mean_rstd, void* T1a, void* T1b, const void* tw_row,
-                            int njobs, const mc_xc_geom* geom, void* stream);
+                            int njobs, const mc_xc_geom* geom, const int* row_chord /* NULL or as in
+                            mc_xc_rows_forward_stats */, void* stream);
 
 /* Column-transform engine of K2 / the near-window K3: 0 = automatic (H == 4096 with at most
  * 512 kept rows at either end of the spectrum -> register-resident radix-16 transform;

@@ -712,9 +712,9 @@ def test_wave512_patch_rows_match_workgroup_engine(dev):
     st = stream_ptr(dev)
     Ua, Ub, Ra, Rb, Sa = (torch.zeros((n, gm.nkx, gm.ny, 2), device=dev) for _ in range(5))
     check(lib.mc_xc_rows_forward_dual(ptr(img), ptr(off), w, ptr(ea), ptr(eb), ptr(pl.mask), ptr(stats), ptr(Ua),
-                                      ptr(Ub), ptr(pl.tw_row), n, gm, st), "dual")
+                                      ptr(Ub), ptr(pl.tw_row), n, gm, ptr(pl.chord), st), "dual")  # chord-clamped loads
     check(lib.mc_xc_rows_forward_dual(ptr(img), ptr(off), w, ptr(ea), None, ptr(pl.mask), ptr(stats), ptr(Sa), None,
-                                      ptr(pl.tw_row), n, gm, st), "single")
+                                      ptr(pl.tw_row), n, gm, None, st), "single")  # box-clamped loads
     check(lib.mc_xc_rows_forward(ptr(img), ptr(off), w, ptr(ea), ptr(pl.mask), ptr(stats), ptr(Ra), ptr(pl.tw_row),
                                  n, gm, st), "wg a")
     check(lib.mc_xc_rows_forward(ptr(img), ptr(off), w, ptr(eb), ptr(pl.mask), ptr(stats), ptr(Rb), ptr(pl.tw_row),

@@ -48,7 +48,7 @@ SIGNATURES = {
     "mc_xc_row_engine": [i32],
     "mc_xc_col_engine": [i32],
     "mc_xc_rows_forward": [vp, vp, i64, vp, vp, vp, vp, vp, i32, GP, vp],
-    "mc_xc_rows_forward_dual": [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, GP, vp],
+    "mc_xc_rows_forward_dual": [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, GP, vp, vp],
     "mc_xc_rows_forward_stats": [vp, vp, i64, vp, vp, vp, vp, i32, GP, i32, i32, i32, i32, vp, vp, vp, vp, vp],
     "mc_xc_cols_forward": [vp, vp, vp, vp, i32, GP, vp],
     "mc_xc_cols_forward_fix": [vp, vp, vp, vp, i32, GP, vp, vp, vp],

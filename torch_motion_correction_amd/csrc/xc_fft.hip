@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256) void xc_rows_fwd_wave512(
     const float* __restrict__ src, const int64_t* __restrict__ job_off, int64_t row_stride,
     const int* __restrict__ expo_a, const int* __restrict__ expo_b, const float* __restrict__ mask,
     const float* __restrict__ mean_rstd, cfloat* __restrict__ T1a, cfloat* __restrict__ T1b,
-    const cfloat* __restrict__ tw_row, XcGeom g) {
+    const cfloat* __restrict__ tw_row, XcGeom g, const int2* __restrict__ chord) {
   __shared__ __attribute__((aligned(16))) wf2 slabs[4][WF5_SLAB];
   __shared__ __attribute__((aligned(16))) wf2 tab[WF5_TWA + WF5_TWB + WF5_TWK];
   const wf2* twA = tab;
@@ -591,13 +591,15 @@ __global__ __launch_bounds__(256) void xc_rows_fwd_wave512(
   const int r16 = grp * WF5_ROWS_PER_WG;
   const int rounds = min(WF5_ROWS_PER_WG / 8, (g.ny - r16) / 8);  // ny % 8 == 0
   const int nrows = rounds > 0 ? 2 * rounds : 0;
-  const int xlo = g.x0, xhi = g.x1 - 2;  // both even: a pair of samples is in or out as a whole
+  const int bxlo = g.x0, bxhi = g.x1 - 2;  // both even: a pair of samples is in or out as a whole
   __syncthreads();
   wf2 Xae[2], Xbe[2];  // bins of the even row of the current pair
 #pragma unroll 1
   for (int rr = 0; rr < nrows; ++rr) {
     const int r = r16 + (rr >> 1) * 8 + 2 * wv + (rr & 1);
     const int y = g.y0 + r;
+    // with a chord table: only this row's chord of the mask disk is fetched (21 % fewer samples)
+    const int xlo = chord ? chord[y].x : bxlo, xhi = chord ? chord[y].y + 2 : bxhi;
     int tl = t;
     asm volatile("" : "+v"(tl));  // per-row addresses are re-derived, not carried (registers)
     const float* row = base + (int64_t)y * row_stride;
@@ -1554,7 +1556,7 @@ static int rows_forward_impl(const float* src, const int64_t* job_off, int64_t r
 int mc_xc_rows_forward_dual(const float* src, const int64_t* job_off, int64_t row_stride,
                             const int* expo_a, const int* expo_b, const float* mask,
                             const float* mean_rstd, void* T1a, void* T1b, const void* tw_row,
-                            int njobs, const mc_xc_geom* q, void* stream) {
+                            int njobs, const mc_xc_geom* q, const int* row_chord, void* stream) {
   XcGeom g;
   int rc = geom_from(q, &g, true, false);
   if (rc) return rc;
@@ -1566,11 +1568,11 @@ int mc_xc_rows_forward_dual(const float* src, const int64_t* job_off, int64_t ro
   if (expo_b)
     hipLaunchKernelGGL(xc_rows_fwd_wave512<true>, grid, dim3(256), 0, (hipStream_t)stream, src, job_off,
                        row_stride, expo_a, expo_b, mask, mean_rstd, (cfloat*)T1a, (cfloat*)T1b,
-                       (const cfloat*)tw_row, g);
+                       (const cfloat*)tw_row, g, (const int2*)row_chord);
   else
     hipLaunchKernelGGL(xc_rows_fwd_wave512<false>, grid, dim3(256), 0, (hipStream_t)stream, src, job_off,
                        row_stride, expo_a, (const int*)nullptr, mask, mean_rstd, (cfloat*)T1a,
-                       (cfloat*)nullptr, (const cfloat*)tw_row, g);
+                       (cfloat*)nullptr, (const cfloat*)tw_row, g, (const int2*)row_chord);
   return mc_check_launch();
 }
 

@@ -119,7 +119,8 @@ def _forward_spectra(src, job_off, row_stride, job_expo, pl, stats, use_mask=Tru
             expo_b = job_expo_b[a : a + n] if dual else None
             check(lib.mc_xc_rows_forward_dual(ptr(src), ptr(off), row_stride, ptr(expo), ptr(expo_b),
                                               ptr(pl.mask), ptr(stats), ptr(T1), ptr(T1b), ptr(pl.tw_row),
-                                              n, g, st), "mc_xc_rows_forward_dual")
+                                              n, g, ptr(pl.chord) if USE_ROW_CHORDS else None, st),
+                  "mc_xc_rows_forward_dual")
         else:
             check(_k1(lib, g, dev, src, off, row_stride, expo, pl.mask if use_mask else None, stats, T1,
                       pl.tw_row, n, st), "xc rows forward")
