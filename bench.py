@@ -163,7 +163,7 @@ def main():
     achieved = alg_bytes / (warp_ms * 1e-3) / 1e9
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # N = 1 only (contract)
         import oracle
 
         n = min(args.cpu_frames, t)
@@ -182,7 +182,7 @@ def main():
     # Secondary workload (reported, never the headline value): BASELINE.json configs[2], local
     # motion on a K3-sized stack -- 1024-px patches (6 x 10), B-spline warp, frame sum.
     secondary = None
-    if rank == 0 and not args.no_secondary:
+    if rank == 0 and world == 1 and not args.no_secondary:
         try:
             del out
             torch.cuda.empty_cache()
