@@ -853,12 +853,15 @@ def test_patches_1024_near_window_search_with_sub_pixel(mc, dev, strategy):
 
 
 @pytest.mark.parametrize("dtype", [torch.uint8, torch.int16, torch.float16, torch.float32])
-def test_condition_movie_matches_the_example_pipeline(mc, dev, dtype):
+@pytest.mark.parametrize("hw", [(70, 90), (72, 96), (64, 2056)])
+def test_condition_movie_matches_the_example_pipeline(mc, dev, dtype, hw):
     """gain multiply + per-frame mean-zero (examples/ttMotion.py:90-121, 174-199) straight from
-    the storage type, against the example's numpy arithmetic."""
+    the storage type, against the example's numpy arithmetic.  (70, 90): h*w % 8 != 0, the
+    per-frame kernels; the others: the tiled kernels (gain tile held in registers over the frames),
+    (64, 2056) with more than one workgroup and a partial last one."""
     g = torch.Generator().manual_seed(3)
-    raw = (torch.rand(3, 70, 90, generator=g) * 40).to(dtype)
-    gain = torch.rand(70, 90, generator=g) * 0.4 + 0.8
+    raw = (torch.rand(3, *hw, generator=g) * 40).to(dtype)
+    gain = torch.rand(*hw, generator=g) * 0.4 + 0.8
     got = mc.condition_movie(raw.to(dev), gain.to(dev)).cpu()
     x = raw.float().numpy().astype(np.float64) * gain.numpy().astype(np.float64)
     ref = torch.from_numpy((x - x.mean(axis=(1, 2), keepdims=True)).astype(np.float32))

@@ -195,6 +195,100 @@ __global__ __launch_bounds__(256) void cond_apply_kernel(const void* __restrict_
     out[base + i] = cond_load<KIND>(raw, base + i) * (gain ? gain[i] : 1.f) - mean;
 }
 
+// Vector form (hw % 8 == 0, 16-byte aligned buffers): 8 pixels per thread -- 8-byte (u8) to 32-byte
+// (f32) loads, two float4 stores.  The gain reference is as large as a frame and is read again for
+// every frame (5.4 GB per 40 x 4096^2 stack and pass, against 0.67 GB of 8-bit samples): a workgroup
+// therefore takes COND_FR consecutive frames per pixel tile with the gain values in registers.  All
+// 40 frames per tile were tried too: that scatters every workgroup's accesses over the whole stack
+// and is slower than no reuse at all.
+template <int KIND>
+__device__ __forceinline__ void cond_load8(const void* p, int64_t i, float (&v)[8]) {
+  if (KIND == 0) {
+    const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(p) + i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = (float)((q.x >> (8 * k)) & 0xffu);
+      v[4 + k] = (float)((q.y >> (8 * k)) & 0xffu);
+    }
+  } else if (KIND == 1) {
+    const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const short*>(p) + i);
+    const unsigned int u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[2 * k] = (float)(short)(u[k] & 0xffffu);
+      v[2 * k + 1] = (float)(short)(u[k] >> 16);
+    }
+  } else if (KIND == 2) {
+    const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(p) + i);
+    const unsigned int u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[2 * k] = __half2float(__ushort_as_half((unsigned short)(u[k] & 0xffffu)));
+      v[2 * k + 1] = __half2float(__ushort_as_half((unsigned short)(u[k] >> 16)));
+    }
+  } else {
+    const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + i);
+    const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + i + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+}
+
+#define COND_FR 8  // frames per workgroup pass: the gain values of a pixel tile are used COND_FR times
+template <int KIND, bool APPLY>
+__global__ __launch_bounds__(256) void cond_vec_kernel(const void* __restrict__ raw,
+                                                       const float* __restrict__ gain, int64_t hw,
+                                                       int nframes, double* __restrict__ sums,
+                                                       float* __restrict__ out) {
+  const int f0 = blockIdx.y * COND_FR;
+  float mean[COND_FR];
+  double s[COND_FR];
+#pragma unroll
+  for (int ff = 0; ff < COND_FR; ++ff) {
+    s[ff] = 0.0;
+    mean[ff] = (APPLY && sums && f0 + ff < nframes) ? (float)(sums[f0 + ff] / (double)hw) : 0.f;
+  }
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < hw; i += (int64_t)gridDim.x * 256 * 8) {
+    float g[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g[k] = 1.f;
+    if (gain) {
+      const float4 a = *reinterpret_cast<const float4*>(gain + i), b = *reinterpret_cast<const float4*>(gain + i + 4);
+      g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w; g[4] = b.x; g[5] = b.y; g[6] = b.z; g[7] = b.w;
+    }
+#pragma unroll
+    for (int ff = 0; ff < COND_FR; ++ff) {
+      if (f0 + ff >= nframes) break;
+      const int64_t base = (int64_t)(f0 + ff) * hw;
+      float v[8];
+      cond_load8<KIND>(raw, base + i, v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] *= g[k];
+      if (APPLY) {
+        const float m = mean[ff];
+        float* o = out + base + i;
+        *reinterpret_cast<float4*>(o) = make_float4(v[0] - m, v[1] - m, v[2] - m, v[3] - m);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(v[4] - m, v[5] - m, v[6] - m, v[7] - m);
+      } else {
+        s[ff] += (double)(((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])));
+      }
+    }
+  }
+  if (!APPLY) {
+    __shared__ double part[COND_FR][4];
+#pragma unroll
+    for (int ff = 0; ff < COND_FR; ++ff) {
+      double r = s[ff];
+      for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off);
+      if ((threadIdx.x & 63) == 0) part[ff][threadIdx.x >> 6] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < COND_FR && f0 + (int)threadIdx.x < nframes) {
+      const int ff = threadIdx.x;
+      atomicAdd(&sums[f0 + ff], (part[ff][0] + part[ff][1]) + (part[ff][2] + part[ff][3]));
+    }
+  }
+}
+
 // ------------------------------------------------------------------ statistics
 __global__ __launch_bounds__(256) void box_stats_partial(const float* __restrict__ stack, int h,
                                                          int w, int hl, int hu, int wl, int wu,
@@ -324,6 +418,34 @@ int mc_condition_movie(const void* raw, int kind, const float* gain, int nframes
   if (!raw || !out || nframes < 1 || hw < 1 || kind < 0 || kind > 3 || (mean_zero && !sums))
     return MC_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
+  const bool tiled = (hw % 8 == 0) && ((reinterpret_cast<uintptr_t>(raw) & (kind == 0 ? 7 : 15)) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
+                     (!gain || (reinterpret_cast<uintptr_t>(gain) & 15) == 0) && hw / 8 / 256 < 0x7fffffff;
+  if (tiled) {
+    if (mean_zero) {
+      hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * nframes, st);
+      if (e != hipSuccess) return (int)e;
+    }
+    int64_t tb = (hw / 8 + 255) / 256;
+    if (tb > 2048) tb = 2048;
+    const dim3 tgrid((unsigned)tb, (nframes + COND_FR - 1) / COND_FR);
+#define MC_COND_T(K)                                                                                    \
+  do {                                                                                                  \
+    if (mean_zero)                                                                                      \
+      hipLaunchKernelGGL((cond_vec_kernel<K, false>), tgrid, dim3(256), 0, st, raw, gain, hw, nframes,    \
+                         sums, (float*)nullptr);                                                        \
+    hipLaunchKernelGGL((cond_vec_kernel<K, true>), tgrid, dim3(256), 0, st, raw, gain, hw, nframes,       \
+                       mean_zero ? sums : (double*)nullptr, out);                                       \
+  } while (0)
+    switch (kind) {
+      case 0: MC_COND_T(0); break;
+      case 1: MC_COND_T(1); break;
+      case 2: MC_COND_T(2); break;
+      default: MC_COND_T(3); break;
+    }
+#undef MC_COND_T
+    return mc_check_launch();
+  }
   int64_t blocks = (hw + 256 * 8 - 1) / (256 * 8);
   if (blocks > 2048) blocks = 2048;
   dim3 grid((unsigned)blocks, nframes);
