@@ -301,10 +301,26 @@ __global__ __launch_bounds__(256) void box_stats_partial(const float* __restrict
   if (r1 > hu) r1 = hu;
   const float* frame = stack + (int64_t)f * h * w;
   double s = 0.0, q = 0.0;
+  // 16-byte loads when every row segment of the box is 16-byte aligned and a multiple of 4 long
+  const bool vec = ((w | wl | (wu - wl)) & 3) == 0 && (reinterpret_cast<uintptr_t>(stack) & 15) == 0 &&
+                   ((((int64_t)h * w) & 3) == 0);
   for (int y = r0; y < r1; ++y) {
     const float* row = frame + (int64_t)y * w;
     float ps = 0.f, pq = 0.f;
     int n = 0;
+    if (vec) {
+      for (int x = wl + 4 * threadIdx.x; x < wu; x += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(row + x);
+        ps += (v.x + v.y) + (v.z + v.w);
+        pq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        if (++n == 4) {  // flush the fp32 partials every 16 samples, as the scalar loop does
+          s += ps; q += pq; ps = 0.f; pq = 0.f; n = 0;
+        }
+      }
+      s += ps;
+      q += pq;
+      continue;
+    }
     for (int x = wl + threadIdx.x; x < wu; x += 256) {
       const float v = row[x];
       ps += v;
