@@ -394,3 +394,24 @@ def test_three_operation_division_is_the_correctly_rounded_quotient():
             e = rn32(Fraction(float(x)) - Fraction(float(q)) * Fraction(float(d)))
             q1 = rn32(Fraction(float(q)) + Fraction(float(e)) * Fraction(float(r)))
             assert q1 == rn32(Fraction(float(x)) / Fraction(float(d))), (n, x)
+
+
+def test_row_chords_bracket_every_nonzero_mask_value():
+    """plan.row_chords: the per-row clamp range K1 uses must contain every non-zero mask sample
+    (a missed one would be replaced by a clamped neighbour) and is tight to 4-sample quads."""
+    mask = tp.circle(40.0, (128, 160), smoothing_radius=20.0)
+    ch = plan.row_chords(mask)
+    assert ch.shape == (128, 2) and ch.dtype == torch.int32
+    for y in range(128):
+        nz = torch.nonzero(mask[y]).flatten()
+        lo, hi = int(ch[y, 0]), int(ch[y, 1])
+        assert lo % 4 == 0 and hi % 4 == 0 and 0 <= lo <= hi <= 156
+        if len(nz):
+            assert lo <= int(nz[0]) < lo + 4 and hi <= int(nz[-1]) < hi + 4
+        else:
+            assert lo == hi == 80
+    # the reference's central statistics box lies inside the chords of the reference's mask
+    h = w = 256
+    m = tp.circle(min(h, w) / 4, (h, w), smoothing_radius=min(h, w) / 8)
+    c = plan.row_chords(m)[int(0.25 * h):int(0.75 * h)]
+    assert bool((c[:, 0] <= int(0.25 * w)).all()) and bool((c[:, 1] + 4 >= int(0.75 * w)).all())
