@@ -274,7 +274,7 @@ int mc_xc_rows_inverse_store(const void* T2, float* out, const int64_t* out_off,
 /* ---- generic transform lengths (Bluestein): any even W (rows), any H (columns) ------ */
 /* One line plan (host struct of device pointers): tw_m = exp(-2 pi i k/M) (M entries),
  * chirp = exp(-+ i pi j^2/n) (n entries; - for forward, + for inverse transforms),
- * bspec = FFT_M(wrapped conj(chirp)) / M (M entries); M = power of two >= 2n-1, <= 8192.
+ * bspec = FFT_M(wrapped conj(chirp)) / M (M entries); M = power of two >= 2n-1, <= 16384.
  * n is W/2 for the row functions and H for the column functions. */
 typedef struct mc_xc_line {
   const void* tw_m;
@@ -289,7 +289,8 @@ typedef struct mc_xc_line {
 /* Same contracts and layouts as mc_xc_rows_forward / mc_xc_cols_forward /
  * mc_xc_cols_inverse (+ Fourier-shift mode when `shifts` != NULL) /
  * mc_xc_rows_inverse_argmax (out == NULL) and mc_xc_rows_inverse_store (out != NULL),
- * without the power-of-two restriction: 4 <= W <= 8192 even, 2 <= H <= 4096.
+ * without the power-of-two restriction: 4 <= W <= 16384 even, 2 <= H <= 8192 (a row line plus
+ * its staged bins must fit 160 KB of LDS: MC_ERR_ARG otherwise).
  * tw_row = exp(-2 pi i k / W), W entries. */
 int mc_xcg_rows_forward(const float* src, const int64_t* job_off, int64_t row_stride,
                         const int* job_expo, const float* mask, const float* mean_rstd, void* T1,

@@ -483,10 +483,12 @@ def test_rigid_warp_odd_widths(mc, dev, shape):
 
 @pytest.mark.parametrize("t,h,w,ps", [(6, 96, 120, 1.0), (5, 100, 64, 1.0), (4, 64, 100, 1.3),
                                       (5, 250, 372, 1.0), (3, 124, 126, 0.9), (3, 1000, 4096, 1.0),
-                                      (3, 200, 1440, 1.0)])
+                                      (3, 200, 1440, 1.0), (3, 4100, 128, 1.0), (3, 128, 8200, 1.0)])
 def test_global_estimate_on_arbitrary_even_sizes(mc, dev, t, h, w, ps):
     """chirp-z rows and/or columns: integer shifts must equal the oracle's exactly.
     (3, 200, 1440): the output-pruned chirp-z row plan (M = 1024 instead of 2048).
+    (3, 4100, 128) / (3, 128, 8200): columns / inverse rows beyond 4096 points: chirp-z lines of
+    M = 16384 (frames up to 8192 x 16384, e.g. 8184 x 11520 super-resolution movies).
     (3, 1000, 4096): wave-per-row K1 with a mask support of 760 rows (47 full 16-row
     workgroups + a tail of 8) feeding chirp-z columns."""
     st, _, _ = drift_stack(t, h, w, seed=h * 7 + w)

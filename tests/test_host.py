@@ -101,9 +101,26 @@ def test_unsupported_sizes_fail_loudly():
     with pytest.raises(NotImplementedError, match="even widths"):
         plan.xc_geometry(4092, 5761, 0.1, 1000, 500)  # odd width
     with pytest.raises(NotImplementedError, match="even widths"):
-        plan.xc_geometry(8184, 11520, 0.1, 2000, 1000)  # beyond the 8192 x 4096 limit
+        plan.xc_geometry(8200, 11520, 0.1, 2000, 1000)  # beyond the 8192-row limit
+    with pytest.raises(NotImplementedError, match="even widths"):
+        plan.xc_geometry(4096, 16400, 0.1, 1000, 500)  # beyond the 16384-column limit
     with pytest.raises(NotImplementedError, match="M="):
-        plan.line_plan(5760, -1, "cpu")
+        plan.line_plan(8200, -1, "cpu")
+    with pytest.raises(NotImplementedError, match="160 KB"):
+        plan.full_geometry(8184, 11520)  # the full spectrum of a super-resolution frame (correct_motion_fast)
+
+
+def test_super_resolution_frames_fit_the_band_limited_transforms():
+    """8184 x 11520 (BASELINE config 5 frames): the band-limited estimate runs on chirp-z lines of
+    8192 points (output-pruned forward rows) and 16384 points (columns, inverse rows)."""
+    low, high = plan.band_limits((300, 10), 1.0)
+    g = plan.xc_geometry(8184, 11520, high, 8184 / 4, 8184 / 8)
+    assert (g.nkx, g.kyp + g.kyn) == (1153, 1637) and g.RG >= 1 and 8184 % g.RG == 0
+    fwd, _ = plan.line_plan(5760, -1, "cpu", keep=g.nkx + 1)
+    inv, _ = plan.line_plan(5760, +1, "cpu")
+    col, _ = plan.line_plan(8184, -1, "cpu")
+    assert (fwd.M, fwd.keep, inv.M, col.M) == (8192, g.nkx + 1, 16384, 16384)
+    assert 8 * (plan.bluestein_size(5760) * 17 // 16 + 1 + g.nkx * (g.RG + 1)) <= 160 * 1024
 
 
 def test_k3_geometry_and_chirp_tables():

@@ -1447,9 +1447,9 @@ __global__ __launch_bounds__(MC_WG) void xc_peak_nbhd(const cfloat* __restrict__
 // power-of-two FFT (the other one may be any length handled by the chirp-z kernels)
 static int geom_from(const mc_xc_geom* q, XcGeom* g, bool rows_pow2 = true, bool cols_pow2 = true) {
   if (!q) return MC_ERR_ARG;
-  if (q->W < 4 || (q->W & 1) || q->W > 8192 || q->H < 2 || q->H > 4096) return MC_ERR_UNSUPPORTED;
-  if (rows_pow2 && (!mc_is_pow2(q->W) || q->W < 32)) return MC_ERR_UNSUPPORTED;
-  if (cols_pow2 && (!mc_is_pow2(q->H) || q->H < 16)) return MC_ERR_UNSUPPORTED;
+  if (q->W < 4 || (q->W & 1) || q->W > 16384 || q->H < 2 || q->H > 8192) return MC_ERR_UNSUPPORTED;
+  if (rows_pow2 && (!mc_is_pow2(q->W) || q->W < 32 || q->W > 8192)) return MC_ERR_UNSUPPORTED;
+  if (cols_pow2 && (!mc_is_pow2(q->H) || q->H < 16 || q->H > 4096)) return MC_ERR_UNSUPPORTED;
   if (q->nkx < 1 || q->nkx > q->W / 2 + 1) return MC_ERR_ARG;
   if (q->kyp < 0 || q->kyn < 0 || q->kyp + q->kyn < 1 || q->kyp + q->kyn > q->H) return MC_ERR_ARG;
   if (q->RG < 1 || q->ny < 1 || q->ny % q->RG || q->H % q->RG) return MC_ERR_ARG;
@@ -2130,6 +2130,7 @@ __global__ __launch_bounds__(MC_WG) void xcg_rows_inv(
     MC_DISPATCH_CASE(11, __VA_ARGS__)        \
     MC_DISPATCH_CASE(12, __VA_ARGS__)        \
     MC_DISPATCH_CASE(13, __VA_ARGS__)        \
+    MC_DISPATCH_CASE(14, __VA_ARGS__)        \
     default:                                 \
       return MC_ERR_UNSUPPORTED;             \
   }
@@ -2137,7 +2138,8 @@ __global__ __launch_bounds__(MC_WG) void xcg_rows_inv(
 // geometry check without the power-of-two requirement
 static int geom_from_g(const mc_xc_geom* q, XcGeom* g) {
   if (!q) return MC_ERR_ARG;
-  if (q->W < 4 || (q->W & 1) || q->W > 8192 || q->H < 2 || q->H > 4096) return MC_ERR_UNSUPPORTED;
+  // chirp-z lines of up to M = 16384 points (139 KB of LDS): W / 2 and H up to 8192
+  if (q->W < 4 || (q->W & 1) || q->W > 16384 || q->H < 2 || q->H > 8192) return MC_ERR_UNSUPPORTED;
   if (q->nkx < 1 || q->nkx > q->W / 2 + 1) return MC_ERR_ARG;
   if (q->kyp < 0 || q->kyn < 0 || q->kyp + q->kyn < 1 || q->kyp + q->kyn > q->H) return MC_ERR_ARG;
   if (q->RG < 1 || q->ny < 1 || q->ny % q->RG || q->H % q->RG) return MC_ERR_ARG;
@@ -2152,7 +2154,7 @@ static int geom_from_g(const mc_xc_geom* q, XcGeom* g) {
 static int line_from(const mc_xc_line* l, int n, XcLine* out, int* logm, bool allow_keep = false,
                      int need_keep = 0) {
   if (!l || !l->tw_m || !l->chirp || !l->bspec) return MC_ERR_ARG;
-  if (!mc_is_pow2(l->M) || l->M < 32 || l->M > 8192) return MC_ERR_UNSUPPORTED;
+  if (!mc_is_pow2(l->M) || l->M < 32 || l->M > 16384) return MC_ERR_UNSUPPORTED;
   if (l->keep < 0 || (l->keep > 0 && !allow_keep)) return MC_ERR_ARG;
   if (l->keep > 0) {
     if (l->keep < need_keep || l->M < n + 2 * l->keep - 1) return MC_ERR_ARG;

@@ -70,7 +70,7 @@ def _pow2(n: int) -> bool:
 
 
 def _k1(lib, g, dev, src, off, row_stride, expo, mask, stats, T1, tw_row, n, st):
-    if _pow2(g.W):
+    if planmod.native_width(g.W):
         return lib.mc_xc_rows_forward(ptr(src), ptr(off), row_stride, ptr(expo), ptr(mask), ptr(stats),
                                       ptr(T1), ptr(tw_row), n, g, st)
     line, _ = planmod.line_plan(g.W // 2, -1, dev, keep=g.nkx + 1)  # output-pruned when that shrinks M
@@ -79,7 +79,7 @@ def _k1(lib, g, dev, src, off, row_stride, expo, mask, stats, T1, tw_row, n, st)
 
 
 def _k2(lib, g, dev, T1, filt, S, tw_col, n, st):
-    if _pow2(g.H):
+    if planmod.native_height(g.H):
         return lib.mc_xc_cols_forward(ptr(T1), ptr(filt), ptr(S), ptr(tw_col), n, g, st)
     line, _ = planmod.line_plan(g.H, -1, dev)
     return lib.mc_xcg_cols_forward(ptr(T1), ptr(filt), ptr(S), line, n, g, st)
@@ -153,7 +153,7 @@ def _peaks(S_cur, cur_idx, S_ref, ref_idx, pl, want_nbhd, shift_rows=None, n_shi
     scale = 1.0 / (g.H * g.W)
     # near-window search (+ the 3x3 neighbourhood of the peak when asked): the full map (T2) is
     # a device-side fallback that normally never runs (mc_xc_correlate_argmax)
-    fused = FUSED_SEARCH and _pow2(g.W) and _pow2(g.H) and g.H >= 1024
+    fused = FUSED_SEARCH and planmod.native_width(g.W) and planmod.native_height(g.H) and g.H >= 1024
     scatter = shift_rows is not None and fused and chunk >= npairs  # one call zeroes + fills the table
     if shift_rows is not None and not scatter:
         table, shifts = shifts, torch.empty((npairs, 2), dtype=torch.float32, device=dev)
@@ -171,7 +171,7 @@ def _peaks(S_cur, cur_idx, S_ref, ref_idx, pl, want_nbhd, shift_rows=None, n_shi
                                              ptr(nb[a : a + n]) if want_nbhd else None, ptr(pl.tw_col),
                                              ptr(pl.tw_row), scale, n, g, st), "mc_xc_correlate_argmax")
             continue
-        if _pow2(g.H):
+        if planmod.native_height(g.H):
             check(lib.mc_xc_cols_inverse(ptr(S_cur), ptr(cur_idx[a : a + n]), ptr(S_ref),
                                          ptr(ref_idx[a : a + n]), ptr(T2), ptr(pl.tw_col), scale, n, g,
                                          st), "mc_xc_cols_inverse")
@@ -180,7 +180,7 @@ def _peaks(S_cur, cur_idx, S_ref, ref_idx, pl, want_nbhd, shift_rows=None, n_shi
             check(lib.mc_xcg_cols_inverse(ptr(S_cur), ptr(cur_idx[a : a + n]), ptr(S_ref),
                                           ptr(ref_idx[a : a + n]), None, ptr(T2), line, scale, n, g, st),
                   "mc_xcg_cols_inverse")
-        if _pow2(g.W):
+        if planmod.native_width(g.W):
             check(lib.mc_xc_rows_inverse_argmax(ptr(T2), ptr(pv), ptr(pi), ptr(peaks[a : a + n]),
                                                 ptr(shifts[a : a + n]), ptr(pl.tw_row), n, g, st),
                   "mc_xc_rows_inverse_argmax")
@@ -190,7 +190,7 @@ def _peaks(S_cur, cur_idx, S_ref, ref_idx, pl, want_nbhd, shift_rows=None, n_shi
                                           ptr(shifts[a : a + n]), None, None, 0, ptr(pl.tw_row), line, n,
                                           g, st), "mc_xcg_rows_inverse")
         if want_nbhd:
-            if not _pow2(g.W):
+            if not planmod.native_width(g.W):
                 raise NotImplementedError("sub-pixel neighbourhood needs a power-of-two patch size")
             check(lib.mc_xc_peak_neighbourhood(ptr(T2), ptr(peaks[a : a + n]), ptr(nb[a : a + n]),
                                                ptr(pl.tw_row), n, g, st),
@@ -226,7 +226,7 @@ def _global_spectra(img, pl):
     hl, hu, wl, wu = int(0.25 * h), int(0.75 * h), int(0.25 * w), int(0.75 * w)
     job_off = _cached(("frame_off", str(dev), t, h, w),
                       lambda: torch.arange(t, device=dev, dtype=torch.int64) * (h * w))
-    fused = (_pow2(g.W) and _pow2(g.H) and hl >= g.y0 and hu <= g.y0 + g.ny and wl >= g.x0
+    fused = (planmod.native_width(g.W) and planmod.native_height(g.H) and hl >= g.y0 and hu <= g.y0 + g.ny and wl >= g.x0
              and wu <= g.x1 and wl % 2 == 0 and wu % 2 == 0 and hu > hl and wu > wl)
     if not fused:
         return _forward_spectra(img, job_off, w, None, pl, central_box_stats(img))
@@ -488,7 +488,7 @@ def fourier_shift(img, shifts):
         check(_k1(lib, g, dev, img, off, w, None, None, None, T1, tw_row, n, st), "xc rows forward")
         check(_k2(lib, g, dev, T1, None, S, tw_col, n, st), "xc cols forward")
         # T1 is dead now and has the same footprint as T2: reuse it
-        if _pow2(g.H):
+        if planmod.native_height(g.H):
             check(lib.mc_fourier_shift_cols_inverse(ptr(S), ptr(idx), ptr(shifts[a : a + n]), ptr(T1),
                                                     ptr(tw_col), 1.0 / (h * w), n, g, st),
                   "mc_fourier_shift_cols_inverse")
@@ -496,7 +496,7 @@ def fourier_shift(img, shifts):
             line, _ = planmod.line_plan(g.H, +1, dev)
             check(lib.mc_xcg_cols_inverse(ptr(S), ptr(idx), None, None, ptr(shifts[a : a + n]), ptr(T1),
                                           line, 1.0 / (h * w), n, g, st), "mc_xcg_cols_inverse")
-        if _pow2(g.W):
+        if planmod.native_width(g.W):
             check(lib.mc_xc_rows_inverse_store(ptr(T1), ptr(out), ptr(off), w, ptr(tw_row), n, g, st),
                   "mc_xc_rows_inverse_store")
         else:
@@ -536,14 +536,14 @@ def dose_weighted_sum(img, pixel_spacing, dose_per_frame, pre_exposure=0.0, volt
     zero = torch.zeros((1, 2), device=dev, dtype=torch.float32)
     off0 = torch.zeros(1, device=dev, dtype=torch.int64)
     T2 = T1[:1] if g.ny == g.H else torch.empty((1, g.nkx, g.H, 2), dtype=torch.float32, device=dev)
-    if _pow2(g.H):
+    if planmod.native_height(g.H):
         check(lib.mc_fourier_shift_cols_inverse(ptr(A), ptr(idx), ptr(zero), ptr(T2), ptr(tw_col),
                                                 1.0 / (h * w), 1, g, st), "mc_fourier_shift_cols_inverse")
     else:
         line, _ = planmod.line_plan(g.H, +1, dev)
         check(lib.mc_xcg_cols_inverse(ptr(A), ptr(idx), None, None, ptr(zero), ptr(T2), line,
                                       1.0 / (h * w), 1, g, st), "mc_xcg_cols_inverse")
-    if _pow2(g.W):
+    if planmod.native_width(g.W):
         check(lib.mc_xc_rows_inverse_store(ptr(T2), ptr(out), ptr(off0), w, ptr(tw_row), 1, g, st),
               "mc_xc_rows_inverse_store")
     else:

@@ -38,11 +38,11 @@ def xc_geometry(h: int, w: int, high: float, radius: float, smoothing: float) ->
     """Pruning bounds for an (h, w) transform: which rfft columns / fft rows can be
     non-zero under the band-pass `f <= high`, and which window rows/columns can be
     non-zero under the soft disk mask.  All bounds are conservative supersets."""
-    if not (4 <= w <= 8192 and w % 2 == 0 and 2 <= h <= 4096) or (_is_pow2(w) and w < 32) or (
+    if not (4 <= w <= 16384 and w % 2 == 0 and 2 <= h <= 8192) or (_is_pow2(w) and w < 32) or (
             _is_pow2(h) and h < 16):
         raise NotImplementedError(
-            f"transform size {h}x{w}: libmcorr handles even widths up to 8192 and heights up to 4096 "
-            "(power-of-two lengths natively, other lengths by chirp-z)"
+            f"transform size {h}x{w}: libmcorr handles even widths up to 16384 and heights up to 8192 "
+            "(power-of-two lengths up to 8192 x 4096 natively, everything else by chirp-z)"
         )
     hi32 = np.float32(high)
     fx = np.arange(w // 2 + 1, dtype=np.float32) * np.float32(1.0 / w)
@@ -66,7 +66,8 @@ def xc_geometry(h: int, w: int, high: float, radius: float, smoothing: float) ->
     x0 -= x0 & 1
     x1 += x1 & 1
     n_line = w // 2
-    if _is_pow2(w):
+    native_w = native_width(w)
+    if native_w:
         subgroups = 256 // min(256, max(64, n_line // 8))  # rows transformed side by side (mc_fft.h)
         lines = subgroups * 2 * (n_line + (n_line >> 4) + 1)
         rg = 16
@@ -75,8 +76,17 @@ def xc_geometry(h: int, w: int, high: float, radius: float, smoothing: float) ->
         m = min(bluestein_size(n_line), bluestein_size_for(n_line + 2 * (nkx + 1) - 1))  # line_plan(keep=nkx+1)
         lines = (m + (m >> 4) + 1) + 2 * (nkx + 1)
         rg = 4
-    while rg > subgroups and 8 * (lines + nkx * (rg + 1)) > (LDS_BUDGET if _is_pow2(w) else 150 * 1024):
+    while rg > subgroups and 8 * (lines + nkx * (rg + 1)) > (LDS_BUDGET if native_w else 150 * 1024):
         rg //= 2
+    if not native_w:  # the inverse row pass holds a classic (unpruned) line + nkx * (rg + 1) staged bins
+        mi = bluestein_size(n_line)
+        while rg > 1 and 8 * ((mi + (mi >> 4) + 1) + nkx * (rg + 1)) > 160 * 1024:
+            rg //= 2
+        if max(8 * (lines + nkx * (rg + 1)), 8 * ((mi + (mi >> 4) + 1) + nkx * (rg + 1))) > 160 * 1024:
+            raise NotImplementedError(
+                f"transform size {h}x{w} with {nkx} kept columns: a chirp-z row line plus its staged bins "
+                "exceeds the 160 KB of LDS (band-limited transforms of frames this wide fit; the full "
+                "spectrum that correct_motion_fast needs does not)")
     while rg > 1 and h % rg:
         rg //= 2
     rg = min(rg, h)
@@ -90,6 +100,15 @@ def xc_geometry(h: int, w: int, high: float, radius: float, smoothing: float) ->
 def full_geometry(h: int, w: int) -> XcGeom:
     """No pruning at all (correct_motion_fast needs the full spectrum)."""
     return xc_geometry(h, w, high=10.0, radius=float(max(h, w)), smoothing=0.0)
+
+
+def native_width(w: int) -> bool:
+    """Row transforms of this width run on the power-of-two kernels (else chirp-z)."""
+    return _is_pow2(w) and w <= 8192
+
+
+def native_height(h: int) -> bool:
+    return _is_pow2(h) and h <= 4096
 
 
 def bluestein_size_for(length: int) -> int:
@@ -122,8 +141,8 @@ def line_plan(n: int, direction: int, device, keep: int = 0):
     if key in _LINES:
         return _LINES[key]
     m = bluestein_size_for(n + 2 * keep - 1) if keep > 0 else bluestein_size(n)
-    if m > 8192:
-        raise NotImplementedError(f"transform length {n}: chirp-z needs M={m} > 8192")
+    if m > 16384:
+        raise NotImplementedError(f"transform length {n}: chirp-z needs M={m} > 16384")
     chirp_at = lambda j: np.exp(1j * direction * np.pi * ((j * j) % (2 * n)).astype(np.float64) / n)
     chirp = chirp_at(np.arange(n, dtype=np.int64))
     bw = np.zeros(m, dtype=np.complex128)
