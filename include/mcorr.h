@@ -334,6 +334,17 @@ int mc_local_ncc_grad(const void* spectra, const float* shifts_px, const float* 
                       const float* hx, const float* ab, int npatch, int t, int nkx, int nky,
                       float* partial, void* stream);
 
+/* correct_motion_fast (correct_motion.py:484-496) for frames whose full spectrum does not fit one
+ * row line (more than ~8190 columns): the frame's even and odd columns are transformed as two
+ * (H, W/2) frames (mc_xcg_rows_forward / mc_xcg_cols_forward, full geometry) into S -- (2 nframes,
+ * W/4 + 1, H) complex, job j = even columns of frame j, job j + nframes = odd columns -- and this
+ * call applies, in place, the radix-2 butterfly to the bins of the full spectrum, the phase ramp
+ * exp(-2 pi i (fy sy + fx sx)) at each bin's own frequency (shifts_px (nframes, 2) = (y, x)), and the
+ * inverse butterfly; the two halves are then inverse-transformed with zero shifts and interleaved.
+ * W % 4 == 0; nkx must be W/4 + 1. */
+int mc_polyphase_fourier_shift(void* S, const float* shifts_px, int nframes, int nkx, int H, int W,
+                               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

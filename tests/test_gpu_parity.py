@@ -1100,3 +1100,22 @@ def test_local_motion_1024_patches_take_the_wave_engine(dev):
     loss.backward()
     assert abs(loss.item() - total.item()) <= 2e-4 * abs(total.item())
     assert float((nd.grad.cpu() - new.grad).abs().max() / new.grad.abs().max()) <= 2e-4
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 128), (2, 100, 132), (2, 96, 120), (2, 33, 72)])
+def test_polyphase_fourier_shift_matches_direct_path_and_oracle(mc, dev, shape):
+    """correct_motion_fast through the x-polyphase form (even / odd columns transformed separately,
+    csrc/polyphase.hip) -- the path frames wider than ~8190 columns take -- forced on small frames."""
+    from torch_motion_correction_amd import engine
+
+    g = torch.Generator().manual_seed(sum(shape))
+    img = torch.randn(*shape, generator=g)
+    sh = torch.randn(2, shape[0], 1, 1, generator=g) * 3
+    ref = oracle.correct_motion_fast(img, sh.clone())
+    direct = mc.correct_motion_fast(img.to(dev), sh.clone().to(dev))
+    engine.POLYPHASE_FOURIER_SHIFT = True
+    try:
+        poly = mc.correct_motion_fast(img.to(dev), sh.clone().to(dev))
+    finally:
+        engine.POLYPHASE_FOURIER_SHIFT = False
+    assert rel_err(poly, ref) <= 2e-5 and rel_err(poly, direct) <= 2e-5

@@ -466,13 +466,72 @@ def pixel_shifts(lattice, h, w, pixel_spacing):
 # ------------------------------------------------------------------ a19: Fourier shift
 
 
+POLYPHASE_FOURIER_SHIFT = False  # tests: force the x-polyphase form on frames that do not need it
+
+
+def _fourier_shift_polyphase(img, shifts):
+    """fourier_shift for frames whose full spectrum does not fit one row line (csrc/polyphase.hip):
+    even and odd columns are transformed as two (h, w/2) frames, one pointwise pass applies the
+    radix-2 butterfly + phase ramp + inverse butterfly, the halves go back and are interleaved."""
+    lib = _lib.load()
+    t, h, w = img.shape
+    if w % 4:
+        raise NotImplementedError(f"frames of {w} columns: the polyphase Fourier shift needs a width divisible by 4")
+    dev = img.device
+    w2 = w // 2
+    g = planmod.full_geometry(h, w2)
+    tw_row, tw_col = planmod.get_twiddles(w2, dev), planmod.get_twiddles(h, dev)
+    out = torch.empty_like(img)
+    per_frame = 2 * g.nkx * g.H * 8
+    chunk = max(1, min(t, WORKSPACE_BYTES // (2 * per_frame)))
+    T1 = torch.empty((2 * chunk, g.nkx, g.ny, 2), dtype=torch.float32, device=dev)
+    S = torch.empty((2 * chunk, g.nkx, g.nky, 2), dtype=torch.float32, device=dev)
+    st = stream_ptr(dev)
+    shifts = shifts.to(dev, torch.float32).contiguous()
+    zero = torch.zeros((2 * chunk, 2), dtype=torch.float32, device=dev)
+    for a in range(0, t, chunk):
+        n = min(chunk, t - a)
+        sub = torch.cat([img[a:a + n, :, 0::2], img[a:a + n, :, 1::2]], dim=0).contiguous()  # (2n, h, w2)
+        off = torch.arange(2 * n, device=dev, dtype=torch.int64) * (h * w2)
+        idx = torch.arange(2 * n, device=dev, dtype=torch.int32)
+        check(_k1(lib, g, dev, sub, off, w2, None, None, None, T1, tw_row, 2 * n, st), "xc rows forward")
+        check(_k2(lib, g, dev, T1, None, S, tw_col, 2 * n, st), "xc cols forward")
+        check(lib.mc_polyphase_fourier_shift(ptr(S), ptr(shifts[a:a + n]), n, g.nkx, h, w, st),
+              "mc_polyphase_fourier_shift")
+        if planmod.native_height(g.H):
+            check(lib.mc_fourier_shift_cols_inverse(ptr(S), ptr(idx), ptr(zero), ptr(T1), ptr(tw_col),
+                                                    1.0 / (h * w2), 2 * n, g, st), "mc_fourier_shift_cols_inverse")
+        else:
+            line, _ = planmod.line_plan(g.H, +1, dev)
+            check(lib.mc_xcg_cols_inverse(ptr(S), ptr(idx), None, None, ptr(zero), ptr(T1), line,
+                                          1.0 / (h * w2), 2 * n, g, st), "mc_xcg_cols_inverse")
+        res = torch.empty_like(sub)
+        if planmod.native_width(g.W):
+            check(lib.mc_xc_rows_inverse_store(ptr(T1), ptr(res), ptr(off), w2, ptr(tw_row), 2 * n, g, st),
+                  "mc_xc_rows_inverse_store")
+        else:
+            line, _ = planmod.line_plan(g.W // 2, +1, dev)
+            check(lib.mc_xcg_rows_inverse(ptr(T1), None, None, None, None, ptr(res), ptr(off), w2,
+                                          ptr(tw_row), line, 2 * n, g, st), "mc_xcg_rows_inverse")
+        out[a:a + n, :, 0::2] = res[:n]
+        out[a:a + n, :, 1::2] = res[n:]
+    return out
+
+
 def fourier_shift(img, shifts):
     """irfft2(rfft2(img) * exp(-2 pi i (fy sy + fx sx))) per frame; shifts (t,2) px
     (correct_motion.py:484-496)."""
     lib = _lib.load()
     t, h, w = img.shape
     dev = img.device
-    g = planmod.full_geometry(h, w)
+    if POLYPHASE_FOURIER_SHIFT:
+        return _fourier_shift_polyphase(img, shifts)
+    try:
+        g = planmod.full_geometry(h, w)
+    except NotImplementedError:
+        if w % 4 == 0 and w <= 16384 and h <= 8192:
+            return _fourier_shift_polyphase(img, shifts)  # too wide for one row line: even / odd columns
+        raise
     tw_row, tw_col = planmod.get_twiddles(w, dev), planmod.get_twiddles(h, dev)
     out = torch.empty_like(img)
     per_frame = g.nkx * g.H * 8
