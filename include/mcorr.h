@@ -344,6 +344,14 @@ int mc_local_ncc_grad(const void* spectra, const float* shifts_px, const float* 
  * W % 4 == 0; nkx must be W/4 + 1. */
 int mc_polyphase_fourier_shift(void* S, const float* shifts_px, int nframes, int nkx, int H, int W,
                                void* stream);
+/* mc_dose_accumulate in the same form: S holds the spectra of the even (jobs 0..nframes-1) and odd
+ * (jobs nframes..2 nframes-1) columns of a chunk of frames; A (2, W/4 + 1, H) complex accumulates
+ * the weighted butterfly outputs and, on the last chunk, becomes the spectra of the even / odd
+ * columns of the exposure-weighted sum (inverse-transform both with zero shifts and interleave). */
+int mc_polyphase_dose_accumulate(const void* S, int nframes, int frame0, int total_frames, void* A,
+                                 int nkx, int H, int W, float pixel_size, float pre_exposure,
+                                 float dose_per_frame, float voltage, int first, int last,
+                                 void* stream);
 
 #ifdef __cplusplus
 }

@@ -1119,3 +1119,22 @@ def test_polyphase_fourier_shift_matches_direct_path_and_oracle(mc, dev, shape):
     finally:
         engine.POLYPHASE_FOURIER_SHIFT = False
     assert rel_err(poly, ref) <= 2e-5 and rel_err(poly, direct) <= 2e-5
+
+
+@pytest.mark.parametrize("shape,ps,dose", [((5, 64, 128), 1.0, 1.5), ((4, 90, 132), 0.83, 0.8), ((3, 33, 72), 1.3, 2.0)])
+def test_polyphase_dose_weighted_sum_matches_direct_path_and_oracle(mc, dev, shape, ps, dose):
+    """dose_weighted_sum through the x-polyphase form (the path of frames wider than ~8190 columns),
+    forced on small frames: equal to the direct path and to the oracle."""
+    from torch_motion_correction_amd import engine
+
+    g = torch.Generator().manual_seed(sum(shape))
+    m = torch.randn(*shape, generator=g) * 2.0 + 5.0
+    ref = oracle.dose_weighted_sum(m, ps, dose, pre_exposure=0.4, voltage=300.0)
+    direct = mc.dose_weighted_sum(m.to(dev), ps, dose, pre_exposure=0.4).cpu()
+    engine.POLYPHASE_FOURIER_SHIFT = True
+    try:
+        poly = mc.dose_weighted_sum(m.to(dev), ps, dose, pre_exposure=0.4).cpu()
+    finally:
+        engine.POLYPHASE_FOURIER_SHIFT = False
+    scale = float(ref.abs().max())
+    assert float((poly - ref).abs().max()) <= 1e-4 * scale and float((poly - direct).abs().max()) <= 2e-5 * scale

@@ -78,6 +78,7 @@ SIGNATURES = {
     "mc_condition_movie": [vp, i32, vp, i32, i64, i32, vp, vp, vp],
     "mc_dose_accumulate": [vp, i32, i32, i32, vp, i32, i32, f32, f32, f32, f32, i32, i32, vp],
     "mc_polyphase_fourier_shift": [vp, vp, i32, i32, i32, i32, vp],
+    "mc_polyphase_dose_accumulate": [vp, i32, i32, i32, vp, i32, i32, i32, f32, f32, f32, f32, i32, i32, vp],
     "mc_local_loss_tiles": [i32, i32, vp],
     "mc_local_loss_sums": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp],
     "mc_local_ncc_grad": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp],

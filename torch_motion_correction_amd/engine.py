@@ -565,6 +565,64 @@ def fourier_shift(img, shifts):
     return out
 
 
+def _inverse_frames(lib, g, S, n, h, w, dev, st):
+    """irfft2 of n full spectra S (n, nkx, H) -> (n, h, w) frames (zero-shift Fourier-shift path)."""
+    tw_row, tw_col = planmod.get_twiddles(w, dev), planmod.get_twiddles(h, dev)
+    out = torch.empty((n, h, w), dtype=torch.float32, device=dev)
+    idx = torch.arange(n, device=dev, dtype=torch.int32)
+    zero = torch.zeros((n, 2), device=dev, dtype=torch.float32)
+    off = torch.arange(n, device=dev, dtype=torch.int64) * (h * w)
+    T2 = torch.empty((n, g.nkx, g.H, 2), dtype=torch.float32, device=dev)
+    if planmod.native_height(g.H):
+        check(lib.mc_fourier_shift_cols_inverse(ptr(S), ptr(idx), ptr(zero), ptr(T2), ptr(tw_col),
+                                                1.0 / (h * w), n, g, st), "mc_fourier_shift_cols_inverse")
+    else:
+        line, _ = planmod.line_plan(g.H, +1, dev)
+        check(lib.mc_xcg_cols_inverse(ptr(S), ptr(idx), None, None, ptr(zero), ptr(T2), line,
+                                      1.0 / (h * w), n, g, st), "mc_xcg_cols_inverse")
+    if planmod.native_width(g.W):
+        check(lib.mc_xc_rows_inverse_store(ptr(T2), ptr(out), ptr(off), w, ptr(tw_row), n, g, st),
+              "mc_xc_rows_inverse_store")
+    else:
+        line, _ = planmod.line_plan(g.W // 2, +1, dev)
+        check(lib.mc_xcg_rows_inverse(ptr(T2), None, None, None, None, ptr(out), ptr(off), w,
+                                      ptr(tw_row), line, n, g, st), "mc_xcg_rows_inverse")
+    return out
+
+
+def _dose_weighted_sum_polyphase(img, pixel_spacing, dose_per_frame, pre_exposure, voltage):
+    """dose_weighted_sum for frames too wide for one row line: even / odd columns (csrc/polyphase.hip)."""
+    lib = _lib.load()
+    t, h, w = img.shape
+    if w % 4:
+        raise NotImplementedError(f"frames of {w} columns: the polyphase form needs a width divisible by 4")
+    dev = img.device
+    w2 = w // 2
+    g = planmod.full_geometry(h, w2)
+    tw_row, tw_col = planmod.get_twiddles(w2, dev), planmod.get_twiddles(h, dev)
+    per_frame = 2 * g.nkx * g.H * 8
+    chunk = max(1, min(t, WORKSPACE_BYTES // (2 * per_frame)))
+    T1 = torch.empty((2 * chunk, g.nkx, g.ny, 2), dtype=torch.float32, device=dev)
+    S = torch.empty((2 * chunk, g.nkx, g.nky, 2), dtype=torch.float32, device=dev)
+    A = torch.empty((2, g.nkx, g.nky, 2), dtype=torch.float32, device=dev)
+    st = stream_ptr(dev)
+    for a in range(0, t, chunk):
+        n = min(chunk, t - a)
+        sub = torch.cat([img[a:a + n, :, 0::2], img[a:a + n, :, 1::2]], dim=0).contiguous()
+        off = torch.arange(2 * n, device=dev, dtype=torch.int64) * (h * w2)
+        check(_k1(lib, g, dev, sub, off, w2, None, None, None, T1, tw_row, 2 * n, st), "xc rows forward")
+        check(_k2(lib, g, dev, T1, None, S, tw_col, 2 * n, st), "xc cols forward")
+        check(lib.mc_polyphase_dose_accumulate(ptr(S), n, a, t, ptr(A), g.nkx, h, w, float(pixel_spacing),
+                                               float(pre_exposure), float(dose_per_frame), float(voltage),
+                                               1 if a == 0 else 0, 1 if a + n >= t else 0, st),
+              "mc_polyphase_dose_accumulate")
+    halves = _inverse_frames(lib, g, A, 2, h, w2, dev, st)
+    out = torch.empty((h, w), dtype=torch.float32, device=dev)
+    out[:, 0::2] = halves[0]
+    out[:, 1::2] = halves[1]
+    return out
+
+
 def dose_weighted_sum(img, pixel_spacing, dose_per_frame, pre_exposure=0.0, voltage=300.0):
     """sum_f irfft2(q_f * rfft2(frame_f)): the exposure-filtered frame sum of the reference's
     example pipeline (examples/ttMotion.py:331-351, 398) with ONE inverse transform per movie:
@@ -573,7 +631,14 @@ def dose_weighted_sum(img, pixel_spacing, dose_per_frame, pre_exposure=0.0, volt
     lib = _lib.load()
     t, h, w = img.shape
     dev = img.device
-    g = planmod.full_geometry(h, w)
+    if POLYPHASE_FOURIER_SHIFT:
+        return _dose_weighted_sum_polyphase(img, pixel_spacing, dose_per_frame, pre_exposure, voltage)
+    try:
+        g = planmod.full_geometry(h, w)
+    except NotImplementedError:
+        if w % 4 == 0 and w <= 16384 and h <= 8192:
+            return _dose_weighted_sum_polyphase(img, pixel_spacing, dose_per_frame, pre_exposure, voltage)
+        raise
     tw_row, tw_col = planmod.get_twiddles(w, dev), planmod.get_twiddles(h, dev)
     per_frame = g.nkx * g.H * 8
     chunk = max(1, min(t, WORKSPACE_BYTES // (2 * per_frame)))
