@@ -289,7 +289,8 @@ typedef struct mc_xc_line {
 /* Same contracts and layouts as mc_xc_rows_forward / mc_xc_cols_forward /
  * mc_xc_cols_inverse (+ Fourier-shift mode when `shifts` != NULL) /
  * mc_xc_rows_inverse_argmax (out == NULL) and mc_xc_rows_inverse_store (out != NULL),
- * without the power-of-two restriction: 4 <= W <= 16384 even, 2 <= H <= 8192 (a row line plus
+ * without the power-of-two restriction: 4 <= W <= 16384 even or W <= 8191 odd (odd widths: the
+ * row line plan has n = W points, one real sample each, instead of W / 2), 2 <= H <= 8192 (a row line plus
  * its staged bins must fit 160 KB of LDS: MC_ERR_ARG otherwise).
  * tw_row = exp(-2 pi i k / W), W entries. */
 int mc_xcg_rows_forward(const float* src, const int64_t* job_off, int64_t row_stride,

@@ -531,9 +531,27 @@ def test_correct_motion_fast_on_arbitrary_sizes(mc, dev, shape):
                    oracle.correct_motion_fast(img, sh.clone())) <= 2e-5
 
 
-def test_odd_width_is_rejected_loudly(mc, dev):
+def test_odd_widths_run_on_unpacked_row_lines(mc, dev):
+    """Odd widths (the reference's example movie is 959 x 927): the chirp-z row kernels take one real
+    sample per line point instead of the two-per-point packing.  Global estimate, Fourier shift and
+    dose-weighted sum against the oracle."""
+    st, _, _ = drift_stack(5, 121, 135, seed=4)
+    got = mc.estimate_global_motion(st.to(dev), 1.0).cpu()
+    ref, ccs = oracle.estimate_global_motion(st, 1.0, return_cc=True)
+    for f, cc in ccs.items():
+        top = torch.topk(cc.flatten(), 2).values
+        if float(top[0] - top[1]) > 1e-5 * float(top[0].abs()):
+            assert torch.equal(got[:, f], ref[:, f]), (f, got[:, f].flatten(), ref[:, f].flatten())
+    g = torch.Generator().manual_seed(8)
+    img = torch.randn(3, 64, 75, generator=g)
+    sh = torch.randn(2, 3, 1, 1, generator=g) * 3
+    assert rel_err(mc.correct_motion_fast(img.to(dev), sh.clone().to(dev)), oracle.correct_motion_fast(img, sh.clone())) <= 2e-5
+    m = img * 2.0 + 5.0
+    d = mc.dose_weighted_sum(m.to(dev), 1.0, 1.2).cpu()
+    r = oracle.dose_weighted_sum(m, 1.0, 1.2)
+    assert float((d - r).abs().max()) <= 1e-4 * float(r.abs().max())
     with pytest.raises(NotImplementedError, match="even widths"):
-        mc.estimate_global_motion(torch.randn(3, 64, 65, device=dev), 1.0)
+        mc.estimate_global_motion(torch.randn(2, 64, 8193, device=dev), 1.0)
 
 
 # ------------------------------------------------------------------ wave-per-row K1
@@ -1138,3 +1156,22 @@ def test_polyphase_dose_weighted_sum_matches_direct_path_and_oracle(mc, dev, sha
         engine.POLYPHASE_FOURIER_SHIFT = False
     scale = float(ref.abs().max())
     assert float((poly - ref).abs().max()) <= 1e-4 * scale and float((poly - direct).abs().max()) <= 2e-5 * scale
+
+
+def test_example_movie_shape_runs_the_reference_flow(mc, dev):
+    """The reference's example movie is 40 x 959 x 927 (examples/example.ipynb: odd height and odd
+    width).  Its flow -- global estimate, patch estimate with the global field as prior (which
+    pre-corrects with correct_motion_fast), correct_motion -- on a stack of that frame size; the
+    global shifts against the oracle."""
+    st, dy, dx = drift_stack(8, 959, 927, seed=6)
+    d = st.to(dev)
+    glob = mc.estimate_global_motion(d, 1.35)
+    ref, ccs = oracle.estimate_global_motion(st, 1.35, return_cc=True)
+    for f, cc in ccs.items():
+        top = torch.topk(cc.flatten(), 2).values
+        if float(top[0] - top[1]) > 1e-5 * float(top[0].abs()):
+            assert torch.equal(glob.cpu()[:, f], ref[:, f]), f
+    field, centres = mc.estimate_motion_cross_correlation_patches(d, 1.35, patch_sidelength=256, deformation_field=glob)
+    assert field.shape[:2] == (2, 8) and centres.shape[-1] == 3 and torch.isfinite(field).all()
+    out = mc.correct_motion(d, field, 1.35)
+    assert out.shape == st.shape and torch.isfinite(out).all()

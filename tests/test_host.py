@@ -99,7 +99,8 @@ def test_full_geometry_keeps_everything():
 
 def test_unsupported_sizes_fail_loudly():
     with pytest.raises(NotImplementedError, match="even widths"):
-        plan.xc_geometry(4092, 5761, 0.1, 1000, 500)  # odd width
+        plan.xc_geometry(4092, 8193, 0.1, 1000, 500)  # odd widths: one sample per line point, at most 8191
+    assert plan.xc_geometry(959, 927, 0.1, 927 / 4, 927 / 8).nkx == 93  # the reference's example movie size
     with pytest.raises(NotImplementedError, match="even widths"):
         plan.xc_geometry(8200, 11520, 0.1, 2000, 1000)  # beyond the 8192-row limit
     with pytest.raises(NotImplementedError, match="even widths"):

@@ -417,7 +417,7 @@ int mc_xc_filter(float* filt, const mc_xc_geom* q, float low, float high, float 
 int mc_dose_accumulate(const void* S, int nframes, int frame0, int total_frames, void* A, int W,
                        int H, float pixel_size, float pre_exposure, float dose_per_frame,
                        float voltage, int first, int last, void* stream) {
-  if (!S || !A || nframes < 1 || frame0 < 0 || total_frames < frame0 + nframes || W < 2 || (W & 1) ||
+  if (!S || !A || nframes < 1 || frame0 < 0 || total_frames < frame0 + nframes || W < 2 ||
       H < 1 || !(pixel_size > 0.f) || !(dose_per_frame >= 0.f))
     return MC_ERR_ARG;
   const float vscale = voltage >= 300.f ? 1.0f : (voltage >= 200.f ? 0.8f : 0.75f);

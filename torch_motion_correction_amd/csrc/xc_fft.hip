@@ -1447,7 +1447,7 @@ __global__ __launch_bounds__(MC_WG) void xc_peak_nbhd(const cfloat* __restrict__
 // power-of-two FFT (the other one may be any length handled by the chirp-z kernels)
 static int geom_from(const mc_xc_geom* q, XcGeom* g, bool rows_pow2 = true, bool cols_pow2 = true) {
   if (!q) return MC_ERR_ARG;
-  if (q->W < 4 || (q->W & 1) || q->W > 16384 || q->H < 2 || q->H > 8192) return MC_ERR_UNSUPPORTED;
+  if (q->W < 4 || q->W > 16384 || ((q->W & 1) && q->W > 8191) || q->H < 2 || q->H > 8192) return MC_ERR_UNSUPPORTED;
   if (rows_pow2 && (!mc_is_pow2(q->W) || q->W < 32 || q->W > 8192)) return MC_ERR_UNSUPPORTED;
   if (cols_pow2 && (!mc_is_pow2(q->H) || q->H < 16 || q->H > 4096)) return MC_ERR_UNSUPPORTED;
   if (q->nkx < 1 || q->nkx > q->W / 2 + 1) return MC_ERR_ARG;
@@ -1455,7 +1455,8 @@ static int geom_from(const mc_xc_geom* q, XcGeom* g, bool rows_pow2 = true, bool
   if (q->RG < 1 || q->ny < 1 || q->ny % q->RG || q->H % q->RG) return MC_ERR_ARG;
   if (rows_pow2 && (q->RG % (MC_WG / fft_threads(q->W / 2)))) return MC_ERR_ARG;  // rows vs sub-groups
   if (q->y0 < 0 || q->y0 + q->ny > q->H) return MC_ERR_ARG;
-  if (q->x0 < 0 || q->x1 > q->W || (q->x0 & 1) || (q->x1 & 1) || q->x0 >= q->x1) return MC_ERR_ARG;
+  if (q->x0 < 0 || q->x1 > q->W || q->x0 >= q->x1) return MC_ERR_ARG;
+  if (!(q->W & 1) && ((q->x0 & 1) || (q->x1 & 1))) return MC_ERR_ARG;
   g->W = q->W; g->H = q->H; g->nkx = q->nkx; g->kyp = q->kyp; g->kyn = q->kyn;
   g->y0 = q->y0; g->ny = q->ny; g->x0 = q->x0; g->x1 = q->x1; g->RG = q->RG;
   return MC_OK;
@@ -1914,6 +1915,27 @@ __global__ __launch_bounds__(MC_WG) void xcg_rows_fwd(
     const int y = g.y0 + grp * RG + r;
     const float* row = base + (int64_t)y * row_stride;
     const float* mrow = mask + (int64_t)y * g.W;
+    if (g.W & 1) {
+      // odd width: no two-samples-per-point packing; the row is a length-W complex line with zero
+      // imaginary parts and the wanted bins are the first nkx outputs as they are
+      auto load1 = [&](int x) {
+        cfloat v = cmake(0.f, 0.f);
+        if (x >= g.x0 && x < g.x1) {
+          v.x = (row[x] - mean) * rstd;
+          if (expo > 0) {
+            const float m0 = mrow[x];
+            for (int e = 0; e < expo; ++e) v.x *= m0;
+          }
+        }
+        return v;
+      };
+      auto store1 = [&](int k, cfloat v) {
+        if (k < g.nkx) stg[k * (RG + 1) + r] = v;
+      };
+      wg_bluestein<M>(line, tid, ln.tw_m, ln.chirp, ln.bspec, n, load1, store1, ln.keep);
+      __syncthreads();
+      continue;
+    }
     auto load = [&](int j) {
       const int x = 2 * j;
       cfloat v = cmake(0.f, 0.f);
@@ -2065,6 +2087,29 @@ __global__ __launch_bounds__(MC_WG) void xcg_rows_inv(
   int bi = 0x7fffffff;
   for (int r = 0; r < RG; ++r) {
     const int y = grp * RG + r;
+    if (g.W & 1) {
+      // odd width: the full Hermitian line of W points, X[W - k] = conj(X[k]); outputs are real
+      auto load1 = [&](int k) {
+        cfloat v = cmake(0.f, 0.f);
+        if (k < g.nkx) {
+          v = stg[k * (RG + 1) + r];
+          if (k == 0) v.y = 0.f;
+        } else if (n - k < g.nkx) {
+          v = cconj(stg[(n - k) * (RG + 1) + r]);
+        }
+        return v;
+      };
+      if constexpr (EPI == 0) {
+        auto store1 = [&](int j, cfloat v) { cand_merge(bv, bi, v.x, y * g.W + j); };
+        wg_bluestein<M>(line, tid, ln.tw_m, ln.chirp, ln.bspec, n, load1, store1);
+      } else {
+        float* orow = out_real + out_off[p] + (int64_t)y * out_stride;
+        auto store1 = [&](int j, cfloat v) { orow[j] = v.x; };
+        wg_bluestein<M>(line, tid, ln.tw_m, ln.chirp, ln.bspec, n, load1, store1);
+      }
+      __syncthreads();
+      continue;
+    }
     // c2r pack for a real row of even length W = 2n (same identity as the 2^k path)
     auto load = [&](int k) {
       const int km = n - k;  // in [1, n]
@@ -2139,12 +2184,15 @@ __global__ __launch_bounds__(MC_WG) void xcg_rows_inv(
 static int geom_from_g(const mc_xc_geom* q, XcGeom* g) {
   if (!q) return MC_ERR_ARG;
   // chirp-z lines of up to M = 16384 points (139 KB of LDS): W / 2 and H up to 8192
-  if (q->W < 4 || (q->W & 1) || q->W > 16384 || q->H < 2 || q->H > 8192) return MC_ERR_UNSUPPORTED;
+  // (odd widths: one real sample per point of the line, so at most 8191 columns)
+  if (q->W < 4 || q->W > 16384 || ((q->W & 1) && q->W > 8191) || q->H < 2 || q->H > 8192)
+    return MC_ERR_UNSUPPORTED;
   if (q->nkx < 1 || q->nkx > q->W / 2 + 1) return MC_ERR_ARG;
   if (q->kyp < 0 || q->kyn < 0 || q->kyp + q->kyn < 1 || q->kyp + q->kyn > q->H) return MC_ERR_ARG;
   if (q->RG < 1 || q->ny < 1 || q->ny % q->RG || q->H % q->RG) return MC_ERR_ARG;
   if (q->y0 < 0 || q->y0 + q->ny > q->H) return MC_ERR_ARG;
-  if (q->x0 < 0 || q->x1 > q->W || (q->x0 & 1) || (q->x1 & 1) || q->x0 >= q->x1) return MC_ERR_ARG;
+  if (q->x0 < 0 || q->x1 > q->W || q->x0 >= q->x1) return MC_ERR_ARG;
+  if (!(q->W & 1) && ((q->x0 & 1) || (q->x1 & 1))) return MC_ERR_ARG;  // packed pairs: whole pairs in or out
   g->W = q->W; g->H = q->H; g->nkx = q->nkx; g->kyp = q->kyp; g->kyn = q->kyn;
   g->y0 = q->y0; g->ny = q->ny; g->x0 = q->x0; g->x1 = q->x1; g->RG = q->RG;
   return MC_OK;
@@ -2180,7 +2228,7 @@ int mc_xcg_rows_forward(const float* src, const int64_t* job_off, int64_t row_st
   int rc = geom_from_g(q, &g);
   if (rc) return rc;
   // rows forward needs Z[k] for k < nkx and Z[n - k] for 1 <= k <= nkx: keep >= nkx + 1
-  if ((rc = line_from(line, g.W / 2, &ln, &logm, true, g.nkx + 1))) return rc;
+  if ((rc = line_from(line, (g.W & 1) ? g.W : g.W / 2, &ln, &logm, true, (g.W & 1) ? g.nkx : g.nkx + 1))) return rc;
   if (!src || !job_off || !T1 || !tw_row || njobs < 1) return MC_ERR_ARG;
   const size_t lds = sizeof(cfloat) * ((size_t)lds_len(line->M) + 2 * (g.nkx + 1) + (size_t)g.nkx * (g.RG + 1));
   if (lds > 160 * 1024) return MC_ERR_ARG;
@@ -2244,7 +2292,7 @@ int mc_xcg_rows_inverse(const void* T2, float* part_val, int* part_idx, int* pea
   XcGeom g; XcLine ln; int logm;
   int rc = geom_from_g(q, &g);
   if (rc) return rc;
-  if ((rc = line_from(line, g.W / 2, &ln, &logm))) return rc;
+  if ((rc = line_from(line, (g.W & 1) ? g.W : g.W / 2, &ln, &logm))) return rc;
   if (!T2 || !tw_row || npairs < 1) return MC_ERR_ARG;
   const bool store = out != nullptr;
   if (store ? !out_off : (!part_val || !part_idx || !peaks || !shifts)) return MC_ERR_ARG;

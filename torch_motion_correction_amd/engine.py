@@ -73,7 +73,8 @@ def _k1(lib, g, dev, src, off, row_stride, expo, mask, stats, T1, tw_row, n, st)
     if planmod.native_width(g.W):
         return lib.mc_xc_rows_forward(ptr(src), ptr(off), row_stride, ptr(expo), ptr(mask), ptr(stats),
                                       ptr(T1), ptr(tw_row), n, g, st)
-    line, _ = planmod.line_plan(g.W // 2, -1, dev, keep=g.nkx + 1)  # output-pruned when that shrinks M
+    line, _ = planmod.line_plan(planmod.row_line_length(g.W), -1, dev,
+                                keep=planmod.row_line_keep(g.W, g.nkx))  # output-pruned when that shrinks M
     return lib.mc_xcg_rows_forward(ptr(src), ptr(off), row_stride, ptr(expo), ptr(mask), ptr(stats),
                                    ptr(T1), ptr(tw_row), line, n, g, st)
 
@@ -185,7 +186,7 @@ def _peaks(S_cur, cur_idx, S_ref, ref_idx, pl, want_nbhd, shift_rows=None, n_shi
                                                 ptr(shifts[a : a + n]), ptr(pl.tw_row), n, g, st),
                   "mc_xc_rows_inverse_argmax")
         else:
-            line, _ = planmod.line_plan(g.W // 2, +1, dev)
+            line, _ = planmod.line_plan(planmod.row_line_length(g.W), +1, dev)
             check(lib.mc_xcg_rows_inverse(ptr(T2), ptr(pv), ptr(pi), ptr(peaks[a : a + n]),
                                           ptr(shifts[a : a + n]), None, None, 0, ptr(pl.tw_row), line, n,
                                           g, st), "mc_xcg_rows_inverse")
@@ -510,7 +511,7 @@ def _fourier_shift_polyphase(img, shifts):
             check(lib.mc_xc_rows_inverse_store(ptr(T1), ptr(res), ptr(off), w2, ptr(tw_row), 2 * n, g, st),
                   "mc_xc_rows_inverse_store")
         else:
-            line, _ = planmod.line_plan(g.W // 2, +1, dev)
+            line, _ = planmod.line_plan(planmod.row_line_length(g.W), +1, dev)
             check(lib.mc_xcg_rows_inverse(ptr(T1), None, None, None, None, ptr(res), ptr(off), w2,
                                           ptr(tw_row), line, 2 * n, g, st), "mc_xcg_rows_inverse")
         out[a:a + n, :, 0::2] = res[:n]
@@ -559,7 +560,7 @@ def fourier_shift(img, shifts):
             check(lib.mc_xc_rows_inverse_store(ptr(T1), ptr(out), ptr(off), w, ptr(tw_row), n, g, st),
                   "mc_xc_rows_inverse_store")
         else:
-            line, _ = planmod.line_plan(g.W // 2, +1, dev)
+            line, _ = planmod.line_plan(planmod.row_line_length(g.W), +1, dev)
             check(lib.mc_xcg_rows_inverse(ptr(T1), None, None, None, None, ptr(out), ptr(off), w,
                                           ptr(tw_row), line, n, g, st), "mc_xcg_rows_inverse")
     return out
@@ -584,7 +585,7 @@ def _inverse_frames(lib, g, S, n, h, w, dev, st):
         check(lib.mc_xc_rows_inverse_store(ptr(T2), ptr(out), ptr(off), w, ptr(tw_row), n, g, st),
               "mc_xc_rows_inverse_store")
     else:
-        line, _ = planmod.line_plan(g.W // 2, +1, dev)
+        line, _ = planmod.line_plan(planmod.row_line_length(g.W), +1, dev)
         check(lib.mc_xcg_rows_inverse(ptr(T2), None, None, None, None, ptr(out), ptr(off), w,
                                       ptr(tw_row), line, n, g, st), "mc_xcg_rows_inverse")
     return out
@@ -671,7 +672,7 @@ def dose_weighted_sum(img, pixel_spacing, dose_per_frame, pre_exposure=0.0, volt
         check(lib.mc_xc_rows_inverse_store(ptr(T2), ptr(out), ptr(off0), w, ptr(tw_row), 1, g, st),
               "mc_xc_rows_inverse_store")
     else:
-        line, _ = planmod.line_plan(g.W // 2, +1, dev)
+        line, _ = planmod.line_plan(planmod.row_line_length(g.W), +1, dev)
         check(lib.mc_xcg_rows_inverse(ptr(T2), None, None, None, None, ptr(out), ptr(off0), w,
                                       ptr(tw_row), line, 1, g, st), "mc_xcg_rows_inverse")
     return out[0]

@@ -38,11 +38,11 @@ def xc_geometry(h: int, w: int, high: float, radius: float, smoothing: float) ->
     """Pruning bounds for an (h, w) transform: which rfft columns / fft rows can be
     non-zero under the band-pass `f <= high`, and which window rows/columns can be
     non-zero under the soft disk mask.  All bounds are conservative supersets."""
-    if not (4 <= w <= 16384 and w % 2 == 0 and 2 <= h <= 8192) or (_is_pow2(w) and w < 32) or (
+    if not (4 <= w <= 16384 and (w % 2 == 0 or w <= 8191) and 2 <= h <= 8192) or (_is_pow2(w) and w < 32) or (
             _is_pow2(h) and h < 16):
         raise NotImplementedError(
-            f"transform size {h}x{w}: libmcorr handles even widths up to 16384 and heights up to 8192 "
-            "(power-of-two lengths up to 8192 x 4096 natively, everything else by chirp-z)"
+            f"transform size {h}x{w}: libmcorr handles even widths up to 16384 (odd widths up to 8191) and "
+            "heights up to 8192 (power-of-two lengths up to 8192 x 4096 natively, everything else by chirp-z)"
         )
     hi32 = np.float32(high)
     fx = np.arange(w // 2 + 1, dtype=np.float32) * np.float32(1.0 / w)
@@ -63,9 +63,10 @@ def xc_geometry(h: int, w: int, high: float, radius: float, smoothing: float) ->
     reach = int(math.ceil(radius + smoothing)) + 2
     y0, y1 = max(0, cy - reach), min(h, cy + reach + 1)
     x0, x1 = max(0, cx - reach), min(w, cx + reach + 1)
-    x0 -= x0 & 1
-    x1 += x1 & 1
-    n_line = w // 2
+    if w % 2 == 0:  # two samples per point of the row line: whole pairs are in or out
+        x0 -= x0 & 1
+        x1 += x1 & 1
+    n_line = row_line_length(w)
     native_w = native_width(w)
     if native_w:
         subgroups = 256 // min(256, max(64, n_line // 8))  # rows transformed side by side (mc_fft.h)
@@ -73,7 +74,7 @@ def xc_geometry(h: int, w: int, high: float, radius: float, smoothing: float) ->
         rg = 16
     else:  # chirp-z rows: one line of M = pow2 >= 2*(w/2)-1 points + two small side buffers
         subgroups = 1
-        m = min(bluestein_size(n_line), bluestein_size_for(n_line + 2 * (nkx + 1) - 1))  # line_plan(keep=nkx+1)
+        m = min(bluestein_size(n_line), bluestein_size_for(n_line + 2 * row_line_keep(w, nkx) - 1))  # line_plan(keep=...)
         lines = (m + (m >> 4) + 1) + 2 * (nkx + 1)
         rg = 4
     while rg > subgroups and 8 * (lines + nkx * (rg + 1)) > (LDS_BUDGET if native_w else 150 * 1024):
@@ -100,6 +101,18 @@ def xc_geometry(h: int, w: int, high: float, radius: float, smoothing: float) ->
 def full_geometry(h: int, w: int) -> XcGeom:
     """No pruning at all (correct_motion_fast needs the full spectrum)."""
     return xc_geometry(h, w, high=10.0, radius=float(max(h, w)), smoothing=0.0)
+
+
+def row_line_length(w: int) -> int:
+    """Points of one chirp-z row line: two real samples per complex point for even widths, one for
+    odd widths (no packing identity there)."""
+    return w // 2 if w % 2 == 0 else w
+
+
+def row_line_keep(w: int, nkx: int) -> int:
+    """Outputs the forward row pass needs on either side of zero (plan.line_plan(keep=...)): the
+    packed form also needs the mirror Z[n - k] of every kept bin."""
+    return nkx + 1 if w % 2 == 0 else nkx
 
 
 def native_width(w: int) -> bool:
