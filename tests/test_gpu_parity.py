@@ -1045,6 +1045,9 @@ def test_reference_suite_local_motion(mc, dev):
         assert out.shape == (2, t, 2, 2) and isinstance(out, torch.Tensor) and torch.isfinite(out).all()
     out, traj = mc.estimate_local_motion(image=img, **kw, return_trajectory=True)
     assert out.shape == (2, t, 2, 2) and traj is not None and len(traj.checkpoints) == 2
+    # as the reference's tests call it: CPU image, device=cpu -> staged to the GPU, field returned on the CPU
+    cpu_out = mc.estimate_local_motion(image=img, **{**kw, "device": torch.device("cpu")})
+    assert cpu_out.device.type == "cpu" and cpu_out.shape == (2, t, 2, 2)
 
 
 def _coord_knife(coords, h, w, eps=2e-3):

@@ -338,7 +338,8 @@ def estimate_local_motion(image, pixel_spacing, patch_shape, deformation_field_r
     from . import local_motion
     from .optimization_state import OptimizationTracker
 
-    dev = _out_device(image, device)
+    out_dev = _out_device(image, device)
+    dev = require_gpu(out_dev)  # CPU tensors are staged to the GPU and the field comes back on `out_dev`
     img = _stage(image, dev)
     if grid_type not in ("catmull_rom", "bspline"):
         raise ValueError(f"Invalid grid type: {grid_type}. Must be 'catmull_rom' or 'bspline'.")
@@ -357,6 +358,7 @@ def estimate_local_motion(image, pixel_spacing, patch_shape, deformation_field_r
     final = local_motion.estimate_local_motion(img, float(pixel_spacing), patch_shape, res, init, n_iterations,
                                                b_factor, frequency_range, optimizer_type, grid_type, loss_type,
                                                optimizer_kwargs, trajectory)
+    final = final.to(out_dev)
     return (final, trajectory) if return_trajectory else final
 
 
