@@ -306,6 +306,11 @@ int mc_xcg_rows_inverse(const void* T2, float* part_val, int* part_idx, int* pea
                         float* out, const int64_t* out_off, int64_t out_stride, const void* tw_row,
                         const mc_xc_line* line, int npairs, const mc_xc_geom* geom, void* stream);
 
+/* K6 for any size (same contract as mc_xc_peak_neighbourhood, no twiddle table): the nine values
+ * as direct sums over the kept columns of T2. */
+int mc_xcg_peak_neighbourhood(const void* T2, const int* peaks, float* nb, int npairs,
+                              const mc_xc_geom* geom, void* stream);
+
 /* caller-side frame sum (examples/ttMotion.py:398): sum[h*w] = sum_t frames[t]. */
 int mc_sum_frames(const float* frames, int nframes, int64_t hw, float* sum, void* stream);
 

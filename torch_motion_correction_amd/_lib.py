@@ -74,6 +74,7 @@ SIGNATURES = {
     "mc_xcg_cols_forward": [vp, vp, vp, LP, i32, GP, vp],
     "mc_xcg_cols_inverse": [vp, vp, vp, vp, vp, vp, LP, f32, i32, GP, vp],
     "mc_xcg_rows_inverse": [vp, vp, vp, vp, vp, vp, vp, i64, vp, LP, i32, GP, vp],
+    "mc_xcg_peak_neighbourhood": [vp, vp, vp, i32, GP, vp],
     "mc_sum_frames": [vp, i32, i64, vp, vp],
     "mc_condition_movie": [vp, i32, vp, i32, i64, i32, vp, vp, vp],
     "mc_dose_accumulate": [vp, i32, i32, i32, vp, i32, i32, f32, f32, f32, f32, i32, i32, vp],

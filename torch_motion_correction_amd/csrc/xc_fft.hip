@@ -1875,6 +1875,60 @@ int mc_xc_peak_neighbourhood(const void* T2, const int* peaks, float* nb, const 
 
 }  // extern "C"
 
+// K6 for any width: the nine map values around a peak as direct sums over the kept columns,
+//   cc(y, x) = sum_kx h(kx) Re(T2[p][kx][y] exp(+2 pi i kx x / W)),
+// h = 1 for kx = 0 (and the Nyquist column of an even width), 2 otherwise; the imaginary parts of
+// those self-conjugate columns are dropped as a c2r transform drops them.  nkx terms per value:
+// nothing to transform for 9 values.  kx x is reduced mod W in integers before the sine.
+__global__ __launch_bounds__(MC_WG) void xcg_peak_nbhd(const cfloat* __restrict__ T2, const int* __restrict__ peaks,
+                                                       float* __restrict__ nb, XcGeom g) {
+  const int tid = threadIdx.x;
+  const int p = blockIdx.y, dy = (int)blockIdx.x - 1;
+  const int pk = peaks[p];
+  const int py = pk / g.W, px = pk - py * g.W;
+  const int y = py + dy;
+  float* o = nb + (int64_t)p * 9 + (dy + 1) * 3;
+  if (y < 0 || y >= g.H) {
+    if (tid < 3) o[tid] = __builtin_nanf("");
+    return;
+  }
+  const cfloat* in = T2 + (int64_t)p * g.nkx * g.H + y;
+  float acc[3] = {0.f, 0.f, 0.f};
+  const float invw = 1.0f / (float)g.W;
+  for (int kx = tid; kx < g.nkx; kx += MC_WG) {
+    cfloat v = in[(int64_t)kx * g.H];
+    const bool self = kx == 0 || (!(g.W & 1) && kx == g.W / 2);
+    if (self) v.y = 0.f;
+    const float hk = self ? 1.f : 2.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int x = px + i - 1;
+      if (x < 0 || x >= g.W) continue;
+      const int r = (int)(((int64_t)kx * x) % g.W);
+      float sn, cs;
+      sincospif(2.0f * (float)r * invw, &sn, &cs);
+      acc[i] += hk * (v.x * cs - v.y * sn);
+    }
+  }
+  __shared__ float part[3][MC_WG / 64];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float a = acc[i];
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+    if ((tid & 63) == 0) part[i][tid >> 6] = a;
+  }
+  __syncthreads();
+  if (tid < 3) {
+    const int x = px + tid - 1;
+    float v = __builtin_nanf("");
+    if (x >= 0 && x < g.W) {
+      v = 0.f;
+      for (int w = 0; w < MC_WG / 64; ++w) v += part[tid][w];
+    }
+    o[tid] = v;
+  }
+}
+
 // =====================================================================================
 // Generic transform lengths (Bluestein chirp-z on the power-of-two workgroup FFT).
 // Rows: any EVEN W (real rows are packed into W/2 complex points as in the power-of-two
@@ -2219,6 +2273,17 @@ static int line_from(const mc_xc_line* l, int n, XcLine* out, int* logm, bool al
   (void)hipFuncSetAttribute((const void*)(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))
 
 extern "C" {
+
+int mc_xcg_peak_neighbourhood(const void* T2, const int* peaks, float* nb, int npairs, const mc_xc_geom* q,
+                              void* stream) {
+  XcGeom g;
+  int rc = geom_from_g(q, &g);
+  if (rc) return rc;
+  if (!T2 || !peaks || !nb || npairs < 1) return MC_ERR_ARG;
+  hipLaunchKernelGGL(xcg_peak_nbhd, dim3(3, npairs), dim3(MC_WG), 0, (hipStream_t)stream, (const cfloat*)T2, peaks,
+                     nb, g);
+  return mc_check_launch();
+}
 
 int mc_xcg_rows_forward(const float* src, const int64_t* job_off, int64_t row_stride,
                         const int* job_expo, const float* mask, const float* mean_rstd, void* T1,

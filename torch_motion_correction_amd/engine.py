@@ -190,12 +190,13 @@ def _peaks(S_cur, cur_idx, S_ref, ref_idx, pl, want_nbhd, shift_rows=None, n_shi
             check(lib.mc_xcg_rows_inverse(ptr(T2), ptr(pv), ptr(pi), ptr(peaks[a : a + n]),
                                           ptr(shifts[a : a + n]), None, None, 0, ptr(pl.tw_row), line, n,
                                           g, st), "mc_xcg_rows_inverse")
-        if want_nbhd:
-            if not planmod.native_width(g.W):
-                raise NotImplementedError("sub-pixel neighbourhood needs a power-of-two patch size")
+        if want_nbhd and planmod.native_width(g.W):
             check(lib.mc_xc_peak_neighbourhood(ptr(T2), ptr(peaks[a : a + n]), ptr(nb[a : a + n]),
                                                ptr(pl.tw_row), n, g, st),
                   "mc_xc_peak_neighbourhood")
+        elif want_nbhd:  # any other width: nine direct sums over the kept columns
+            check(lib.mc_xcg_peak_neighbourhood(ptr(T2), ptr(peaks[a : a + n]), ptr(nb[a : a + n]), n, g, st),
+                  "mc_xcg_peak_neighbourhood")
     if shift_rows is not None and not scatter:  # general path: scatter with torch
         table.zero_()
         table[shift_rows.long()] = shifts
