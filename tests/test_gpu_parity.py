@@ -483,12 +483,15 @@ def test_rigid_warp_odd_widths(mc, dev, shape):
 
 @pytest.mark.parametrize("t,h,w,ps", [(6, 96, 120, 1.0), (5, 100, 64, 1.0), (4, 64, 100, 1.3),
                                       (5, 250, 372, 1.0), (3, 124, 126, 0.9), (3, 1000, 4096, 1.0),
-                                      (3, 200, 1440, 1.0), (3, 4100, 128, 1.0), (3, 128, 8200, 1.0)])
+                                      (3, 200, 1440, 1.0), (3, 4100, 128, 1.0), (3, 128, 8200, 1.0),
+                                      (3, 121, 128, 1.0), (2, 959, 1024, 1.0)])
 def test_global_estimate_on_arbitrary_even_sizes(mc, dev, t, h, w, ps):
     """chirp-z rows and/or columns: integer shifts must equal the oracle's exactly.
     (3, 200, 1440): the output-pruned chirp-z row plan (M = 1024 instead of 2048).
     (3, 4100, 128) / (3, 128, 8200): columns / inverse rows beyond 4096 points: chirp-z lines of
     M = 16384 (frames up to 8192 x 16384, e.g. 8184 x 11520 super-resolution movies).
+    (3, 121, 128) / (2, 959, 1024): power-of-two widths whose odd height admits no row grouping for
+    the power-of-two row kernels: chirp-z rows instead.
     (3, 1000, 4096): wave-per-row K1 with a mask support of 760 rows (47 full 16-row
     workgroups + a tail of 8) feeding chirp-z columns."""
     st, _, _ = drift_stack(t, h, w, seed=h * 7 + w)
@@ -522,7 +525,7 @@ def test_pruned_spectrum_on_arbitrary_sizes(dev, h, w, pruned_m):
     assert float((S - sub).abs().max() / sub.abs().max()) <= 5e-6
 
 
-@pytest.mark.parametrize("shape", [(3, 100, 66), (2, 96, 120), (2, 64, 90)])
+@pytest.mark.parametrize("shape", [(3, 100, 66), (2, 96, 120), (2, 64, 90), (2, 77, 64)])
 def test_correct_motion_fast_on_arbitrary_sizes(mc, dev, shape):
     g = torch.Generator().manual_seed(sum(shape))
     img = torch.randn(*shape, generator=g)

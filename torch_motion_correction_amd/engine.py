@@ -70,7 +70,7 @@ def _pow2(n: int) -> bool:
 
 
 def _k1(lib, g, dev, src, off, row_stride, expo, mask, stats, T1, tw_row, n, st):
-    if planmod.native_width(g.W):
+    if planmod.native_rows(g):
         return lib.mc_xc_rows_forward(ptr(src), ptr(off), row_stride, ptr(expo), ptr(mask), ptr(stats),
                                       ptr(T1), ptr(tw_row), n, g, st)
     line, _ = planmod.line_plan(planmod.row_line_length(g.W), -1, dev,
@@ -154,7 +154,7 @@ def _peaks(S_cur, cur_idx, S_ref, ref_idx, pl, want_nbhd, shift_rows=None, n_shi
     scale = 1.0 / (g.H * g.W)
     # near-window search (+ the 3x3 neighbourhood of the peak when asked): the full map (T2) is
     # a device-side fallback that normally never runs (mc_xc_correlate_argmax)
-    fused = FUSED_SEARCH and planmod.native_width(g.W) and planmod.native_height(g.H) and g.H >= 1024
+    fused = FUSED_SEARCH and planmod.native_rows(g) and planmod.native_height(g.H) and g.H >= 1024
     scatter = shift_rows is not None and fused and chunk >= npairs  # one call zeroes + fills the table
     if shift_rows is not None and not scatter:
         table, shifts = shifts, torch.empty((npairs, 2), dtype=torch.float32, device=dev)
@@ -181,7 +181,7 @@ def _peaks(S_cur, cur_idx, S_ref, ref_idx, pl, want_nbhd, shift_rows=None, n_shi
             check(lib.mc_xcg_cols_inverse(ptr(S_cur), ptr(cur_idx[a : a + n]), ptr(S_ref),
                                           ptr(ref_idx[a : a + n]), None, ptr(T2), line, scale, n, g, st),
                   "mc_xcg_cols_inverse")
-        if planmod.native_width(g.W):
+        if planmod.native_rows(g):
             check(lib.mc_xc_rows_inverse_argmax(ptr(T2), ptr(pv), ptr(pi), ptr(peaks[a : a + n]),
                                                 ptr(shifts[a : a + n]), ptr(pl.tw_row), n, g, st),
                   "mc_xc_rows_inverse_argmax")
@@ -190,7 +190,7 @@ def _peaks(S_cur, cur_idx, S_ref, ref_idx, pl, want_nbhd, shift_rows=None, n_shi
             check(lib.mc_xcg_rows_inverse(ptr(T2), ptr(pv), ptr(pi), ptr(peaks[a : a + n]),
                                           ptr(shifts[a : a + n]), None, None, 0, ptr(pl.tw_row), line, n,
                                           g, st), "mc_xcg_rows_inverse")
-        if want_nbhd and planmod.native_width(g.W):
+        if want_nbhd and planmod.native_rows(g):
             check(lib.mc_xc_peak_neighbourhood(ptr(T2), ptr(peaks[a : a + n]), ptr(nb[a : a + n]),
                                                ptr(pl.tw_row), n, g, st),
                   "mc_xc_peak_neighbourhood")
@@ -228,7 +228,7 @@ def _global_spectra(img, pl):
     hl, hu, wl, wu = int(0.25 * h), int(0.75 * h), int(0.25 * w), int(0.75 * w)
     job_off = _cached(("frame_off", str(dev), t, h, w),
                       lambda: torch.arange(t, device=dev, dtype=torch.int64) * (h * w))
-    fused = (planmod.native_width(g.W) and planmod.native_height(g.H) and hl >= g.y0 and hu <= g.y0 + g.ny and wl >= g.x0
+    fused = (planmod.native_rows(g) and planmod.native_height(g.H) and hl >= g.y0 and hu <= g.y0 + g.ny and wl >= g.x0
              and wu <= g.x1 and wl % 2 == 0 and wu % 2 == 0 and hu > hl and wu > wl)
     if not fused:
         return _forward_spectra(img, job_off, w, None, pl, central_box_stats(img))
@@ -508,7 +508,7 @@ def _fourier_shift_polyphase(img, shifts):
             check(lib.mc_xcg_cols_inverse(ptr(S), ptr(idx), None, None, ptr(zero), ptr(T1), line,
                                           1.0 / (h * w2), 2 * n, g, st), "mc_xcg_cols_inverse")
         res = torch.empty_like(sub)
-        if planmod.native_width(g.W):
+        if planmod.native_rows(g):
             check(lib.mc_xc_rows_inverse_store(ptr(T1), ptr(res), ptr(off), w2, ptr(tw_row), 2 * n, g, st),
                   "mc_xc_rows_inverse_store")
         else:
@@ -557,7 +557,7 @@ def fourier_shift(img, shifts):
             line, _ = planmod.line_plan(g.H, +1, dev)
             check(lib.mc_xcg_cols_inverse(ptr(S), ptr(idx), None, None, ptr(shifts[a : a + n]), ptr(T1),
                                           line, 1.0 / (h * w), n, g, st), "mc_xcg_cols_inverse")
-        if planmod.native_width(g.W):
+        if planmod.native_rows(g):
             check(lib.mc_xc_rows_inverse_store(ptr(T1), ptr(out), ptr(off), w, ptr(tw_row), n, g, st),
                   "mc_xc_rows_inverse_store")
         else:
@@ -582,7 +582,7 @@ def _inverse_frames(lib, g, S, n, h, w, dev, st):
         line, _ = planmod.line_plan(g.H, +1, dev)
         check(lib.mc_xcg_cols_inverse(ptr(S), ptr(idx), None, None, ptr(zero), ptr(T2), line,
                                       1.0 / (h * w), n, g, st), "mc_xcg_cols_inverse")
-    if planmod.native_width(g.W):
+    if planmod.native_rows(g):
         check(lib.mc_xc_rows_inverse_store(ptr(T2), ptr(out), ptr(off), w, ptr(tw_row), n, g, st),
               "mc_xc_rows_inverse_store")
     else:
@@ -669,7 +669,7 @@ def dose_weighted_sum(img, pixel_spacing, dose_per_frame, pre_exposure=0.0, volt
         line, _ = planmod.line_plan(g.H, +1, dev)
         check(lib.mc_xcg_cols_inverse(ptr(A), ptr(idx), None, None, ptr(zero), ptr(T2), line,
                                       1.0 / (h * w), 1, g, st), "mc_xcg_cols_inverse")
-    if planmod.native_width(g.W):
+    if planmod.native_rows(g):
         check(lib.mc_xc_rows_inverse_store(ptr(T2), ptr(out), ptr(off0), w, ptr(tw_row), 1, g, st),
               "mc_xc_rows_inverse_store")
     else:

@@ -68,8 +68,17 @@ def xc_geometry(h: int, w: int, high: float, radius: float, smoothing: float) ->
         x1 += x1 & 1
     n_line = row_line_length(w)
     native_w = native_width(w)
+    if native_w:  # the power-of-two row kernels transform `subgroups` rows side by side: RG must be a
+        # multiple of that and divide h; heights that allow no such grouping (odd heights with
+        # narrow frames) take the chirp-z row kernels, which have no such constraint
+        sg = row_subgroups(w)
+        rg0 = 16
+        while rg0 > sg and h % rg0:
+            rg0 //= 2
+        if rg0 < sg or h % rg0:
+            native_w = False
     if native_w:
-        subgroups = 256 // min(256, max(64, n_line // 8))  # rows transformed side by side (mc_fft.h)
+        subgroups = row_subgroups(w)  # rows transformed side by side (mc_fft.h)
         lines = subgroups * 2 * (n_line + (n_line >> 4) + 1)
         rg = 16
     else:  # chirp-z rows: one line of M = pow2 >= 2*(w/2)-1 points + two small side buffers
@@ -113,6 +122,18 @@ def row_line_keep(w: int, nkx: int) -> int:
     """Outputs the forward row pass needs on either side of zero (plan.line_plan(keep=...)): the
     packed form also needs the mirror Z[n - k] of every kept bin."""
     return nkx + 1 if w % 2 == 0 else nkx
+
+
+def row_subgroups(w: int) -> int:
+    """Rows the power-of-two row kernels transform side by side in one workgroup (mc_fft.h)."""
+    return 256 // min(256, max(64, (w // 2) // 8))
+
+
+def native_rows(g) -> bool:
+    """This geometry's row passes run on the power-of-two kernels (xc_geometry falls back to the
+    chirp-z rows when the height admits no row grouping for them: RG then is not a multiple of the
+    side-by-side row count)."""
+    return native_width(g.W) and g.RG % row_subgroups(g.W) == 0
 
 
 def native_width(w: int) -> bool:
