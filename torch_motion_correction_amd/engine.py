@@ -65,10 +65,6 @@ def normalize(img: torch.Tensor, stats: torch.Tensor) -> torch.Tensor:
 # ------------------------------------------------------------------ spectra
 
 
-def _pow2(n: int) -> bool:
-    return n > 0 and (n & (n - 1)) == 0
-
-
 def _k1(lib, g, dev, src, off, row_stride, expo, mask, stats, T1, tw_row, n, st):
     if planmod.native_rows(g):
         return lib.mc_xc_rows_forward(ptr(src), ptr(off), row_stride, ptr(expo), ptr(mask), ptr(stats),
