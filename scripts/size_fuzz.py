@@ -7,10 +7,10 @@ import torch_motion_correction_amd as mc
 dev = torch.device("cuda:0")
 random.seed(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 bad = 0
-special = [32, 64, 128, 256, 33, 63, 65, 127, 129, 255, 257, 100, 250]
+special = [8, 16, 32, 64, 128, 256, 12, 33, 63, 65, 127, 129, 255, 257, 100, 250]
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
-    h = random.choice(special + [random.randint(34, 300)])
-    w = random.choice(special + [random.randint(34, 300)])
+    h = random.choice(special + [random.randint(10, 300)])
+    w = random.choice(special + [random.randint(10, 300)])
     t = random.randint(2, 5)
     try:
         st, _, _ = drift_stack(t, h, w, seed=it)

@@ -38,8 +38,7 @@ def xc_geometry(h: int, w: int, high: float, radius: float, smoothing: float) ->
     """Pruning bounds for an (h, w) transform: which rfft columns / fft rows can be
     non-zero under the band-pass `f <= high`, and which window rows/columns can be
     non-zero under the soft disk mask.  All bounds are conservative supersets."""
-    if not (4 <= w <= 16384 and (w % 2 == 0 or w <= 8191) and 2 <= h <= 8192) or (_is_pow2(w) and w < 32) or (
-            _is_pow2(h) and h < 16):
+    if not (4 <= w <= 16384 and (w % 2 == 0 or w <= 8191) and 2 <= h <= 8192):
         raise NotImplementedError(
             f"transform size {h}x{w}: libmcorr handles even widths up to 16384 (odd widths up to 8191) and "
             "heights up to 8192 (power-of-two lengths up to 8192 x 4096 natively, everything else by chirp-z)"
@@ -138,11 +137,11 @@ def native_rows(g) -> bool:
 
 def native_width(w: int) -> bool:
     """Row transforms of this width run on the power-of-two kernels (else chirp-z)."""
-    return _is_pow2(w) and w <= 8192
+    return _is_pow2(w) and 32 <= w <= 8192
 
 
 def native_height(h: int) -> bool:
-    return _is_pow2(h) and h <= 4096
+    return _is_pow2(h) and 16 <= h <= 4096
 
 
 def bluestein_size_for(length: int) -> int:
