@@ -213,8 +213,9 @@ int mc_field_accumulate(const int* peaks, const float* nb, const int* frames, in
                         float* field, void* stream);
 /* Savitzky-Golay (polyorder 1, mode "interp") along t for each (c,gy,gx), as
  * scipy.signal.savgol_filter at estimate_motion_xc.py:528-529; then (optional)
- * subtraction of the single global mean (xc.py:410).  field_out may alias field_in
- * only if window < 3. */
+ * subtraction of the single global mean (xc.py:410).  Any window 3 <= window <= t, odd or
+ * even (the reference reaches an even one as min(window|1, t) for even t: scipy then centres
+ * the interior mean on x[i-w/2+1 .. i+w/2]).  field_out may alias field_in only if window < 3. */
 int mc_field_smooth_center(const float* field_in, float* field_out, int t, int npatch, int window,
                            int subtract_mean, void* stream);
 
@@ -260,6 +261,11 @@ int mc_warp_rigid_phase(const float* frames, int nframes, int h, int w, const fl
  * shifts in px.  scratch: mc_warp_scratch_bytes(1,h,w,GH,GW). */
 int mc_pixel_shifts(const float* lattice, int GH, int GW, int h, int w, float pixel_spacing,
                     float* scratch, float* out, void* stream);
+/* The same at caller-supplied coordinates -- the `pixel_grid` argument of get_pixel_shifts
+ * (correct_motion.py:136,167-168) when it is not the identity grid: coords_yx (n,2) pixel
+ * coordinates (y,x) of an (h,w) frame -> out (n,2) shifts in px. */
+int mc_pixel_shifts_at(const float* lattice, int GH, int GW, int h, int w, float pixel_spacing,
+                       const float* coords_yx, int64_t n, float* out, void* stream);
 
 /* correct_motion_fast (correct_motion.py:430-498): K3 variant multiplying spectrum
  * idx[p] by exp(-2*pi*i*(fy*sy+fx*sx)), shifts[p]=(sy,sx) px, then inverse columns. */

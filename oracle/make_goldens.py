@@ -193,6 +193,12 @@ def reference_helper_vectors():
         out["ts_in"] = fld.numpy()
         for wdw in (5, 4, 3, 15, 2):
             out[f"ts_out_{wdw}"] = xc._apply_temporal_smoothing(fld.clone(), wdw, torch.device("cpu")).numpy()
+        # even EFFECTIVE window: min(window | 1, t) with an even t below it (scipy accepts an even
+        # window_length in mode="interp": the result is the least-squares line over the whole series)
+        for tt, wdw in ((4, 5), (6, 7), (6, 9), (8, 11), (6, 5)):
+            fe = torch.randn(2, tt, 2, 2, generator=g)
+            out[f"tse_in_{tt}_{wdw}"] = fe.numpy()
+            out[f"tse_out_{tt}_{wdw}"] = xc._apply_temporal_smoothing(fe.clone(), wdw, torch.device("cpu")).numpy()
         # a18 get_pixel_shifts (correct_motion.py:132-185).  It calls array_to_grid_sample under
         # the name it imports from torch_image_interpolation; the reference keeps an identical
         # copy of that function in its own utils.py:9-30, which is what is bound here.
@@ -204,8 +210,136 @@ def reference_helper_vectors():
         pixel_grid = torch.stack([yy, xx], dim=-1)
         out["gps_lattice"] = lattice.numpy()
         out["gps_out"] = cm.get_pixel_shifts(frame, 1.3, lattice, pixel_grid).numpy()
+        # a caller-supplied pixel_grid that is NOT the identity: a sub-grid with fractional
+        # coordinates, a few of them outside the frame (reflection padding of the lattice)
+        sub = torch.rand(9, 11, 2, generator=g) * torch.tensor([44.0, 60.0]) - torch.tensor([4.0, 4.0])
+        out["gps_sub_grid"] = sub.numpy()
+        out["gps_sub_out"] = cm.get_pixel_shifts(frame, 1.3, lattice, sub).numpy()
     np.savez_compressed(os.path.join(GOLD, "reference_helpers.npz"), **out)
     print("wrote reference_helpers.npz", len(out), "arrays")
+
+
+def reference_body_vectors():
+    """tests/golden/reference_bodies_with_standins.npz: the reference's own FUNCTION BODIES --
+    estimate_global_motion (xc.py:21-135), estimate_motion_cross_correlation_patches (:138-411,
+    both strategies, t = 52 so that the memo eviction runs, rigid and full prior fields),
+    correct_motion (cm.py:18-78, both bases) and correct_motion_fast (:430-498) -- executed from
+    /root/reference with the names they import from the five absent packages bound to
+    ``oracle.thirdparty_semantics``.
+
+    THIS FILE DOES NOT PIN THIRD-PARTY SEMANTICS: the stand-ins are this repo's own restatement,
+    so agreement says nothing about circle / b_envelope / bandpass_filter / fourier_shift_dft_2d /
+    the spline grids / sample_image_2d ("parity unpinned" stays).  What it does pin is the
+    RESTATEMENT of the reference's own control flow in oracle/motion.py (ordering of
+    normalisation, pre-correction, memo aliasing Q1/Q2/Q3, accumulation, smoothing, mean
+    subtraction): the oracle must reproduce these outputs bit for bit."""
+    import contextlib
+    import io
+
+    from oracle import thirdparty_semantics as tp
+
+    m = _reference_modules_behind_inert_stubs()
+    xc, utils, dfu, cm = m["estimate_motion_xc"], m["utils"], m["deformation_field_utils"], m["correct_motion"]
+
+    def grid_class(kind):
+        class StandInGrid:
+            def __init__(self, data):
+                self.data = data
+
+            @classmethod
+            def from_grid_data(cls, data):
+                return cls(data)
+
+            def to(self, device):
+                return self
+
+            def __call__(self, tyx):
+                return tp.cubic_spline_grid_3d(self.data, tyx, kind)
+
+        return StandInGrid
+
+    saved = {}
+
+    def bind(mod, name, value):
+        saved[(mod, name)] = getattr(mod, name)
+        setattr(mod, name, value)
+
+    bind(xc, "circle", tp.circle)
+    bind(xc, "b_envelope", tp.b_envelope)
+    bind(utils, "bandpass_filter", tp.bandpass_filter)
+    bind(cm, "fourier_shift_dft_2d", tp.fourier_shift_dft_2d)
+    bind(cm, "coordinate_grid", tp.coordinate_grid)
+    bind(cm, "sample_image_2d", tp.sample_image_2d)
+    bind(cm, "array_to_grid_sample", utils.array_to_grid_sample)  # the reference's own copy
+    for mod in (dfu, cm):
+        bind(mod, "CubicBSplineGrid3d", grid_class("bspline"))
+        bind(mod, "CubicCatmullRomGrid3d", grid_class("catmull_rom"))
+    out = {}
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            mov, stat = blob_stack(True), blob_stack(False)
+            out["blob_global"] = xc.estimate_global_motion(mov, 1.0).numpy()
+            out["blob_global_ref0"] = xc.estimate_global_motion(mov, 1.0, reference_frame=0).numpy()
+            out["blob_global_refm1"] = xc.estimate_global_motion(mov, 1.0, reference_frame=-1).numpy()
+            for s in ("mean_except_current", "middle_frame"):
+                fld, pos = xc.estimate_motion_cross_correlation_patches(mov, 1.0, patch_sidelength=32,
+                                                                        reference_strategy=s)
+                out[f"blob_patches_{s}"] = fld.numpy()
+            out["blob_patch_pos"] = pos.numpy()
+            f22, f11 = torch.zeros(2, 5, 2, 2), torch.zeros(2, 5, 1, 1)
+            for f in range(5):
+                f22[0, f], f22[1, f] = 0.1 * f, 0.05 * f
+                f11[0, f], f11[1, f] = 0.1 * f, 0.05 * f
+            out["blob_correct_cr"] = cm.correct_motion(stat, f22, 1.0).numpy()
+            out["blob_correct_bs"] = cm.correct_motion(stat, f22, 1.0, grid_type="bspline").numpy()
+            out["blob_correct_rigid"] = cm.correct_motion(stat, f11, 1.0).numpy()
+            g11 = f11.clone()
+            out["blob_fast"] = cm.correct_motion_fast(stat, g11).numpy()
+            out["blob_fast_grid_after"] = g11.numpy()  # Q1: negated in place
+
+            st, dy, dx = drift_stack(8, 256, 256)
+            fld = xc.estimate_global_motion(st, 1.0)
+            out["drift_global"] = fld.numpy()
+            out["drift_corrected_sum"] = cm.correct_motion(st, fld, 1.0).sum(0).numpy()
+            pf, pos = xc.estimate_motion_cross_correlation_patches(st, 1.0, patch_sidelength=64)
+            out["drift_patch_field"], out["drift_patch_pos"] = pf.numpy(), pos.numpy()
+            out["drift_patch_corrected_sum"] = cm.correct_motion(st, pf, 1.0, grid_type="bspline").sum(0).numpy()
+            # options: no sub-pixel step / rejection / smoothing, other strategy, window, threshold
+            for i, kw in enumerate((
+                    {"reference_strategy": "middle_frame"},
+                    {"reference_strategy": "middle_frame", "reference_frame": 1},
+                    {"reference_strategy": "middle_frame", "reference_frame": -1},
+                    {"sub_pixel_refinement": False, "outlier_rejection": False},
+                    {"temporal_smoothing": False}, {"smoothing_window_size": 3},
+                    {"outlier_threshold": 1.0}, {"b_factor": 1000, "frequency_range": (200, 20)})):
+                f_, _ = xc.estimate_motion_cross_correlation_patches(st, 1.3, patch_sidelength=64, **kw)
+                out[f"drift_opt{i}"] = f_.numpy()
+            # even effective smoothing window: t = 4 < 5
+            f_, _ = xc.estimate_motion_cross_correlation_patches(st[:4], 1.0, patch_sidelength=64)
+            out["drift_t4"] = f_.numpy()
+            f_, _ = xc.estimate_motion_cross_correlation_patches(st[:6], 1.0, patch_sidelength=64,
+                                                                 smoothing_window_size=7)
+            out["drift_t6_w7"] = f_.numpy()
+            # prior fields (Q1 in-place negation, Q9 order): rigid -> correct_motion_fast, full -> bspline
+            prior = fld.clone()
+            f_, _ = xc.estimate_motion_cross_correlation_patches(st, 1.0, patch_sidelength=64,
+                                                                 deformation_field=prior)
+            out["drift_prior_rigid"], out["drift_prior_rigid_after"] = f_.numpy(), prior.numpy()
+            prior = pf.clone()
+            f_, _ = xc.estimate_motion_cross_correlation_patches(st, 1.0, patch_sidelength=64,
+                                                                 deformation_field=prior)
+            out["drift_prior_full"], out["drift_prior_full_after"] = f_.numpy(), prior.numpy()
+            # t = 52: the 50-entry memo evicts (Q3), both strategies
+            st52, _, _ = drift_stack(52, 96, 96, seed=99, pad=16)
+            for s in ("mean_except_current", "middle_frame"):
+                f_, _ = xc.estimate_motion_cross_correlation_patches(st52, 1.0, patch_sidelength=32,
+                                                                     reference_strategy=s)
+                out[f"t52_{s}"] = f_.numpy()
+    finally:
+        for (mod, name), v in saved.items():
+            setattr(mod, name, v)
+    np.savez_compressed(os.path.join(GOLD, "reference_bodies_with_standins.npz"), **out)
+    print("wrote reference_bodies_with_standins.npz", len(out), "arrays")
 
 
 def blob_stack(moving: bool):
@@ -324,6 +458,7 @@ if __name__ == "__main__":
         reference_vectors()
         reference_helper_vectors()
         reference_local_motion_vectors()
+        reference_body_vectors()
     else:
         print("reference not present: patch_grid_reference.npz not regenerated")
     oracle_vectors()

@@ -433,3 +433,38 @@ def test_row_chords_bracket_every_nonzero_mask_value():
     m = tp.circle(min(h, w) / 4, (h, w), smoothing_radius=min(h, w) / 8)
     c = plan.row_chords(m)[int(0.25 * h):int(0.75 * h)]
     assert bool((c[:, 0] <= int(0.25 * w)).all()) and bool((c[:, 1] + 4 >= int(0.75 * w)).all())
+
+
+def test_launches_refuse_a_device_that_is_not_current(monkeypatch):
+    """libmcorr launches on the CURRENT HIP device; buffers elsewhere must fail loudly, not launch
+    on the wrong GPU (the API enters _lib.device_scope(device) around every call)."""
+    import torch
+    from torch_motion_correction_amd import _lib
+
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 1)
+    with pytest.raises(_lib.McorrError, match="current device"):
+        _lib.stream_ptr(torch.device("cuda:0"))
+    with pytest.raises(_lib.McorrError, match="ROCm device"):
+        _lib.stream_ptr(torch.device("cpu"))
+
+
+def test_reference_frame_normalisation():
+    from torch_motion_correction_amd import _lib
+
+    assert _lib.normalize_frame_index(-1, 5) == 4 and _lib.normalize_frame_index(3, 5) == 3
+    assert _lib.normalize_frame_index(-5, 5) == 0
+    for bad in (5, -6, 100):
+        with pytest.raises(IndexError):
+            _lib.normalize_frame_index(bad, 5)
+    with pytest.raises(TypeError):
+        _lib.normalize_frame_index(1.5, 5)
+
+
+def test_mask_schedule_with_a_negative_reference_key():
+    """-1 and t-1 are two memo entries of the reference's LazyPatchGrid (the key is the raw int):
+    no frame is skipped and the reference entry collects one mask factor per processed frame."""
+    ref_expo, cur_expo, processed, ref_read = lattice.mask_schedule(5, "middle_frame", -1, with_ref_reads=True)
+    assert processed == [0, 1, 2, 3, 4]
+    assert ref_read.tolist() == [0, 1, 2, 3, 4] and cur_expo.tolist() == [0, 0, 0, 0, 0]
+    ref_expo, cur_expo, processed, ref_read = lattice.mask_schedule(5, "middle_frame", 4, with_ref_reads=True)
+    assert processed == [0, 1, 2, 3] and ref_read.tolist() == [0, 1, 2, 3, -1]

@@ -309,6 +309,107 @@ def test_oracle_temporal_smoothing_matches_the_reference(refh):
         assert torch.equal(motion._smooth_time(refh["ts_in"].clone(), wdw), refh[f"ts_out_{wdw}"]), wdw
 
 
+def test_oracle_even_effective_smoothing_window_matches_the_reference(refh):
+    """min(window | 1, t) is EVEN for an even t below it (xc.py:506-512): scipy accepts it."""
+    from oracle import motion
+
+    n = 0
+    for key in refh:
+        if key.startswith("tse_in_"):
+            _, _, tt, wdw = key.split("_")
+            got = motion._smooth_time(refh[key].clone(), int(wdw))
+            assert torch.equal(got, refh[f"tse_out_{tt}_{wdw}"]), key
+            n += 1
+    assert n == 5
+
+
+def test_oracle_pixel_shifts_on_a_caller_grid_match_the_reference(refh):
+    """correct_motion.py:167-168: `pixel_grid` is used, not assumed to be the identity grid."""
+    from oracle import motion
+
+    got = motion.get_pixel_shifts(torch.zeros(37, 53), 1.3, refh["gps_lattice"], refh["gps_sub_grid"])
+    assert torch.equal(got, refh["gps_sub_out"])
+
+
+# ---------------------------------- the reference's own function bodies (stand-ins below them)
+
+
+@pytest.fixture(scope="module")
+def refb():
+    """tests/golden/reference_bodies_with_standins.npz: the reference's estimate_global_motion,
+    estimate_motion_cross_correlation_patches, correct_motion and correct_motion_fast EXECUTED from
+    /root/reference with the absent third-party names bound to oracle.thirdparty_semantics
+    (oracle/make_goldens.py:reference_body_vectors).  Pins the restatement of the reference's own
+    control flow; does NOT pin third-party semantics (parity stays unpinned there)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                        "reference_bodies_with_standins.npz")
+    return {k: torch.from_numpy(v) for k, v in np.load(path).items()}
+
+
+def test_oracle_equals_reference_bodies_blob(refb):
+    mov, stat = blob_stack(True), blob_stack(False)
+    assert torch.equal(oracle.estimate_global_motion(mov, 1.0), refb["blob_global"])
+    assert torch.equal(oracle.estimate_global_motion(mov, 1.0, reference_frame=0), refb["blob_global_ref0"])
+    # a negative reference frame indexes from the end but is never "the current frame": not skipped
+    assert torch.equal(oracle.estimate_global_motion(mov, 1.0, reference_frame=-1), refb["blob_global_refm1"])
+    with pytest.raises(IndexError):
+        oracle.estimate_global_motion(mov, 1.0, reference_frame=5)
+    for s in ("mean_except_current", "middle_frame"):
+        fld, pos = oracle.estimate_motion_cross_correlation_patches(mov, 1.0, patch_sidelength=32,
+                                                                    reference_strategy=s)
+        assert torch.equal(fld, refb[f"blob_patches_{s}"]), s
+        assert torch.equal(pos, refb["blob_patch_pos"])
+    f22, f11 = ramp_field(5, 2), ramp_field(5, 1)
+    assert torch.equal(oracle.correct_motion(stat, f22, 1.0), refb["blob_correct_cr"])
+    assert torch.equal(oracle.correct_motion(stat, f22, 1.0, grid_type="bspline"), refb["blob_correct_bs"])
+    assert torch.equal(oracle.correct_motion(stat, f11, 1.0), refb["blob_correct_rigid"])
+    g11 = f11.clone()
+    assert torch.equal(oracle.correct_motion_fast(stat, g11), refb["blob_fast"])
+    assert torch.equal(g11, refb["blob_fast_grid_after"]) and torch.equal(g11, -f11)  # Q1
+
+
+def test_oracle_equals_reference_bodies_drift(refb):
+    st, _, _ = drift_stack(8, 256, 256)
+    fld = oracle.estimate_global_motion(st, 1.0)
+    assert torch.equal(fld, refb["drift_global"])
+    assert torch.equal(oracle.correct_motion(st, fld, 1.0).sum(0), refb["drift_corrected_sum"])
+    pf, pos = oracle.estimate_motion_cross_correlation_patches(st, 1.0, patch_sidelength=64)
+    assert torch.equal(pf, refb["drift_patch_field"]) and torch.equal(pos, refb["drift_patch_pos"])
+    assert torch.equal(oracle.correct_motion(st, pf, 1.0, grid_type="bspline").sum(0),
+                       refb["drift_patch_corrected_sum"])
+    for i, kw in enumerate((
+            {"reference_strategy": "middle_frame"},
+            {"reference_strategy": "middle_frame", "reference_frame": 1},
+            {"reference_strategy": "middle_frame", "reference_frame": -1},
+            {"sub_pixel_refinement": False, "outlier_rejection": False},
+            {"temporal_smoothing": False}, {"smoothing_window_size": 3},
+            {"outlier_threshold": 1.0}, {"b_factor": 1000, "frequency_range": (200, 20)})):
+        f_, _ = oracle.estimate_motion_cross_correlation_patches(st, 1.3, patch_sidelength=64, **kw)
+        assert torch.equal(f_, refb[f"drift_opt{i}"]), kw
+    f_, _ = oracle.estimate_motion_cross_correlation_patches(st[:4], 1.0, patch_sidelength=64)
+    assert torch.equal(f_, refb["drift_t4"])  # even effective smoothing window (t = 4 < 5)
+    f_, _ = oracle.estimate_motion_cross_correlation_patches(st[:6], 1.0, patch_sidelength=64,
+                                                             smoothing_window_size=7)
+    assert torch.equal(f_, refb["drift_t6_w7"])
+    prior = fld.clone()
+    f_, _ = oracle.estimate_motion_cross_correlation_patches(st, 1.0, patch_sidelength=64,
+                                                             deformation_field=prior)
+    assert torch.equal(f_, refb["drift_prior_rigid"]) and torch.equal(prior, refb["drift_prior_rigid_after"])
+    prior = pf.clone()
+    f_, _ = oracle.estimate_motion_cross_correlation_patches(st, 1.0, patch_sidelength=64,
+                                                             deformation_field=prior)
+    assert torch.equal(f_, refb["drift_prior_full"]) and torch.equal(prior, refb["drift_prior_full_after"])
+
+
+@pytest.mark.parametrize("strategy", ["mean_except_current", "middle_frame"])
+def test_oracle_equals_reference_bodies_t52(refb, strategy):
+    """t = 52 > 50: the reference's memo evicts half its entries (Q3); both strategies."""
+    st52, _, _ = drift_stack(52, 96, 96, seed=99, pad=16)
+    f_, _ = oracle.estimate_motion_cross_correlation_patches(st52, 1.0, patch_sidelength=32,
+                                                             reference_strategy=strategy)
+    assert torch.equal(f_, refb[f"t52_{strategy}"])
+
+
 def test_oracle_pixel_shifts_match_the_reference(refh):
     """correct_motion.py:132-185 (bicubic / reflection / align_corners upsample of the lattice)."""
     from oracle import motion

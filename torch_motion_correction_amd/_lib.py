@@ -68,6 +68,7 @@ SIGNATURES = {
     "mc_warp_rigid": [vp, i32, i32, i32, vp, vp, vp, vp, vp],
     "mc_warp_rigid_phase": [vp, i32, i32, i32, vp, vp, vp, vp, i32, vp],
     "mc_pixel_shifts": [vp, i32, i32, i32, i32, f32, vp, vp, vp],
+    "mc_pixel_shifts_at": [vp, i32, i32, i32, i32, f32, vp, i64, vp, vp],
     "mc_fourier_shift_cols_inverse": [vp, vp, vp, vp, vp, f32, i32, GP, vp],
     "mc_xc_rows_inverse_store": [vp, vp, vp, i64, vp, i32, GP, vp],
     "mc_xcg_rows_forward": [vp, vp, i64, vp, vp, vp, vp, vp, LP, i32, GP, vp],
@@ -128,7 +129,38 @@ def ptr(t):
 
 
 def stream_ptr(device) -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    """Current stream of `device` as a hipStream_t.  libmcorr launches on the CURRENT HIP device,
+    so the buffers' device must be the current one: every entry point of the package runs inside
+    ``device_scope`` (torch.cuda.device); anything that slipped past it fails here instead of
+    launching on the wrong GPU."""
+    d = torch.device(device)
+    if d.type != "cuda":
+        raise McorrError(f"libmcorr buffers must live on a ROCm device, got {d}")
+    cur = torch.cuda.current_device()
+    if d.index is not None and d.index != cur:
+        raise McorrError(f"buffers are on cuda:{d.index} but the current device is cuda:{cur}: "
+                         "enter torch_motion_correction_amd._lib.device_scope(device) first")
+    return C.c_void_p(torch.cuda.current_stream(d).cuda_stream)
+
+
+def device_scope(device):
+    """Context manager making `device` the current HIP device for the kernels enqueued inside
+    (the reference takes ``device=`` / ``image.device`` per call and has no notion of a current
+    device: estimate_motion_xc.py:52-55, correct_motion.py:49-53)."""
+    return torch.cuda.device(torch.device(device))
+
+
+def normalize_frame_index(reference_frame, t: int) -> int:
+    """The reference indexes ``filtered_fft[reference_frame]`` / ``lazy_patch_grid[reference_frame]``
+    (estimate_motion_xc.py:101, :306): Python semantics, negative values count from the end and
+    anything outside [-t, t) raises IndexError.  Returns the wrapped index; no raw user value
+    ever reaches a device-side table."""
+    import operator
+
+    r = operator.index(reference_frame)
+    if not -t <= r < t:
+        raise IndexError(f"index {r} is out of bounds for dimension 0 with size {t}")
+    return r % t
 
 
 def require_gpu(device=None) -> torch.device:

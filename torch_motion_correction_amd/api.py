@@ -17,10 +17,13 @@ peaks).  Q4-Q9 are plain semantics and are always reproduced.
 
 from __future__ import annotations
 
+import functools
+import inspect
+
 import torch
 
 from . import engine
-from ._lib import require_gpu
+from ._lib import device_scope, normalize_frame_index, require_gpu
 
 BUG_COMPATIBLE = True
 RIGID_FAST_PATH = True  # (2,nt,1,1) fields use the separable rigid warp kernel
@@ -44,6 +47,24 @@ def _stage(x: torch.Tensor, dev) -> torch.Tensor:
     return x.detach().to(device=dev, dtype=torch.float32).contiguous()
 
 
+def _on_gpu(fn):
+    """Run `fn` with the GPU it computes on as the CURRENT HIP device (libmcorr launches on the
+    current device; the reference takes ``device=`` / the first tensor's device per call).  The
+    device is chosen exactly as the body does: ``device`` if given, else the first argument's."""
+    sig = inspect.signature(fn)
+
+    @functools.wraps(fn)
+    def scoped(*args, **kwargs):
+        bound = sig.bind(*args, **kwargs)
+        first = next(iter(bound.arguments.values()))
+        device = bound.arguments.get("device")
+        out_dev = first.device if device is None and isinstance(first, torch.Tensor) else device
+        with device_scope(require_gpu(out_dev)):
+            return fn(*args, **kwargs)
+
+    return scoped
+
+
 # ------------------------------------------------------------------ field utilities
 
 
@@ -55,6 +76,7 @@ def image_shifts_to_deformation_field(shifts, pixel_spacing, device=None):
     return (shifts * pixel_spacing).transpose(0, 1)[:, :, None, None]
 
 
+@_on_gpu
 def evaluate_deformation_field(deformation_field, tyx, grid_type="catmull_rom"):
     """(c,nt,nh,nw) spline grid evaluated at (...,3) tyx points in [0,1] -> (...,c)
     (deformation_field_utils.py:9-39).  Points are evaluated one tensor-product row at
@@ -77,6 +99,7 @@ def evaluate_deformation_field(deformation_field, tyx, grid_type="catmull_rom"):
     return vals.reshape(*lead, c).to(out_dev)
 
 
+@_on_gpu
 def evaluate_deformation_field_at_t(deformation_field, t, grid_shape, grid_type="catmull_rom"):
     """(c, H, W) shifts on the linspace(0,1) lattice at time t
     (deformation_field_utils.py:42-93)."""
@@ -89,6 +112,7 @@ def evaluate_deformation_field_at_t(deformation_field, t, grid_shape, grid_type=
     return lat[:, 0].to(out_dev)
 
 
+@_on_gpu
 def resample_deformation_field(deformation_field, target_resolution):
     """Catmull-Rom resample to (nt,nh,nw) (deformation_field_utils.py:96-126)."""
     out_dev = deformation_field.device
@@ -103,6 +127,7 @@ def resample_deformation_field(deformation_field, target_resolution):
 # ------------------------------------------------------------------ estimators
 
 
+@_on_gpu
 def estimate_global_motion(image, pixel_spacing, reference_frame=None, b_factor=500,
                            frequency_range=(300, 10), device=None):
     """Whole-frame cross-correlation shift estimate (estimate_motion_xc.py:21-135).
@@ -113,6 +138,7 @@ def estimate_global_motion(image, pixel_spacing, reference_frame=None, b_factor=
     img = _stage(image, dev)
     t = img.shape[0]
     ref = t // 2 if reference_frame is None else reference_frame
+    normalize_frame_index(ref, t)  # IndexError outside [-t, t), as filtered_fft[ref] (xc.py:101)
     _say(f"Cross-correlation whole image: using frame {ref} as reference")
     shifts = engine.global_shifts(img, ref, float(pixel_spacing), float(b_factor), frequency_range)
     if VERBOSE:
@@ -121,6 +147,7 @@ def estimate_global_motion(image, pixel_spacing, reference_frame=None, b_factor=
     return image_shifts_to_deformation_field(shifts, pixel_spacing).to(out_dev)
 
 
+@_on_gpu
 def estimate_motion_cross_correlation_patches(
     image, pixel_spacing, reference_frame=None, reference_strategy="mean_except_current",
     b_factor=500, frequency_range=(300, 10), patch_sidelength=1024, sub_pixel_refinement=True,
@@ -137,6 +164,10 @@ def estimate_motion_cross_correlation_patches(
     ref = t // 2 if reference_frame is None else reference_frame
     if reference_strategy not in ("middle_frame", "mean_except_current"):
         raise ValueError(f"Unknown reference_strategy: {reference_strategy}")
+    if reference_strategy == "middle_frame":
+        normalize_frame_index(ref, t)  # lazy_patch_grid[ref] (xc.py:306): IndexError outside [-t, t)
+    else:
+        ref = t // 2  # mean_except_current never reads reference_frame (xc.py:310-328)
     if BUG_COMPATIBLE and outlier_rejection and not sub_pixel_refinement:
         # Q12: integer peak coordinates reach torch.std at estimate_motion_xc.py:577
         raise RuntimeError("std and var only support floating point and complex dtypes")
@@ -178,6 +209,7 @@ def estimate_motion(image, pixel_spacing, patch_sidelength=None, **kwargs):
 # ------------------------------------------------------------------ correctors
 
 
+@_on_gpu
 def correct_motion(image, deformation_grid, pixel_spacing, grad=False, grid_type="catmull_rom",
                    device=None):
     """Apply a (2,nt,gh,gw) Angstrom deformation field (correct_motion.py:18-78).
@@ -212,6 +244,7 @@ def _wants_grad(grid) -> bool:
     return any(p.requires_grad for p in params()) if callable(params) else False
 
 
+@_on_gpu
 def correct_motion_two_grids(image, new_deformation_grid, base_deformation_grid, pixel_spacing, grad=True,
                              device=None):
     """correct_motion.py:188-299 -- the frames resampled through the SUM of two spline grids
@@ -255,6 +288,7 @@ class _ForwardOnly(torch.autograd.Function):
                                   "(forward only); use grad=False")
 
 
+@_on_gpu
 def correct_motion_slow(image, deformation_grid, grad=False, device=None):
     """correct_motion.py:302-427 -- the (2,nt,nh,nw) field evaluated (Catmull-Rom) at EVERY pixel
     (t_i, y/(h-1), x/(w-1)) and used as PIXEL shifts (no pixel spacing), then bicubic resampling.
@@ -280,6 +314,7 @@ def correct_motion_slow(image, deformation_grid, grad=False, device=None):
     return out.to(out_dev)
 
 
+@_on_gpu
 def motion_correct_sum(image, deformation_grid, pixel_spacing, grid_type="catmull_rom", device=None,
                        return_frames=False, dose_per_frame=None, pre_exposure=0.0, voltage=300.0):
     """Fused correct_motion + the caller-side ``torch.sum(movie, dim=0)`` of the
@@ -302,6 +337,7 @@ def motion_correct_sum(image, deformation_grid, pixel_spacing, grid_type="catmul
     return (total.to(out_dev), frames.to(out_dev)) if return_frames else total.to(out_dev)
 
 
+@_on_gpu
 def condition_movie(movie, gain=None, mean_zero=True, device=None):
     """Raw detector frames -> the fp32 stack the estimators expect: ``movie * gain`` (a (h,w)
     multiplicative gain reference, already flipped / rotated as needed) and, per frame,
@@ -314,6 +350,7 @@ def condition_movie(movie, gain=None, mean_zero=True, device=None):
     return engine.condition_movie(movie.detach().to(dev), gain, bool(mean_zero)).to(out_dev)
 
 
+@_on_gpu
 def dose_weighted_sum(movie, pixel_spacing, dose_per_frame, pre_exposure=0.0, voltage=300.0, device=None):
     """``sum_f irfft2(q_f * rfft2(frame_f))`` with the Grant & Grigorieff exposure filter
     ``q_f = exp(-0.5 N_f / N_c(|k|))`` normalised by ``sqrt(sum_f q_f^2)``: the reference
@@ -326,6 +363,7 @@ def dose_weighted_sum(movie, pixel_spacing, dose_per_frame, pre_exposure=0.0, vo
                                     float(pre_exposure), float(voltage)).to(out_dev)
 
 
+@_on_gpu
 def estimate_local_motion(image, pixel_spacing, patch_shape, deformation_field_resolution,
                           initial_deformation_field=None, device=None, n_iterations=100, b_factor=500,
                           frequency_range=(300, 10), optimizer_type="adam", grid_type="catmull_rom",
@@ -375,6 +413,7 @@ def _correct_motion_fast_impl(img_dev, deformation_grid, dev, mutate):
     return engine.fourier_shift(img_dev, shifts.to(dev))
 
 
+@_on_gpu
 def correct_motion_fast(image, deformation_grid, device=None):
     """Rigid correction by a Fourier phase ramp (correct_motion.py:430-498); field
     values are used as pixels.  With BUG_COMPATIBLE the caller's `deformation_grid` is
@@ -387,13 +426,25 @@ def correct_motion_fast(image, deformation_grid, device=None):
     return out.to(out_dev)
 
 
+@_on_gpu
 def get_pixel_shifts(frame, pixel_spacing, frame_deformation_grid, pixel_grid=None):
     """(h,w,2) per-pixel shifts in px from a (2,G_h,G_w) Angstrom lattice
-    (correct_motion.py:132-185).  `pixel_grid` is accepted for signature parity; the
-    reference always passes the identity grid coordinate_grid((h,w)), which is what
-    the kernel evaluates."""
+    (correct_motion.py:132-185).  `pixel_grid` (..., 2) holds the (y, x) pixel coordinates to
+    evaluate at (correct_motion.py:167-168); the reference always passes the identity grid
+    coordinate_grid((h,w)), which -- like None -- takes the tabulated kernel; any other grid is
+    evaluated point by point (mc_pixel_shifts_at), result shape = pixel_grid's."""
     out_dev = frame.device
     dev = require_gpu(out_dev)
     h, w = frame.shape[-2:]
-    out = engine.pixel_shifts(_stage(frame_deformation_grid, dev), h, w, float(pixel_spacing))
+    lat = _stage(frame_deformation_grid, dev)
+    if pixel_grid is not None:
+        if pixel_grid.shape[-1] != 2:
+            raise ValueError(f"pixel_grid must have shape (..., 2), got {tuple(pixel_grid.shape)}")
+        grid = _stage(pixel_grid, dev)
+        identity = tuple(grid.shape) == (h, w, 2) and bool(
+            (grid[..., 0] == torch.arange(h, device=dev, dtype=torch.float32)[:, None]).all()
+            and (grid[..., 1] == torch.arange(w, device=dev, dtype=torch.float32)[None, :]).all())
+        if not identity:
+            return engine.pixel_shifts_at(lat, h, w, float(pixel_spacing), grid).to(out_dev)
+    out = engine.pixel_shifts(lat, h, w, float(pixel_spacing))
     return out.to(out_dev)

@@ -151,9 +151,12 @@ __global__ __launch_bounds__(256) void field_smooth_center(const float* __restri
       continue;
     }
     const double cw = 1.0 / (double)window;
+    // scipy's kernel for an even window sits half a sample late (savgol_coeffs pos = w/2 - 0.5,
+    // convolve1d origin w/2): y[i] = mean(x[i-w/2+1 .. i+w/2]); odd: mean(x[i-half .. i+half])
+    const int klo = (window & 1) ? -half : 1 - half;
     for (int i = half; i < t - half; ++i) {
       double a = 0;
-      for (int k = -half; k <= half; ++k) a += (double)x[(int64_t)(i + k) * npatch] * cw;
+      for (int k = klo; k <= half; ++k) a += (double)x[(int64_t)(i + k) * npatch] * cw;
       y[(int64_t)i * npatch] = (float)a;
     }
     // edges: least-squares line through the first / last `window` samples
@@ -217,7 +220,7 @@ int mc_field_accumulate(const int* peaks, const float* nb, const int* frames, in
 int mc_field_smooth_center(const float* field_in, float* field_out, int t, int npatch, int window,
                            int subtract_mean, void* stream) {
   if (!field_in || !field_out || t < 1 || npatch < 1) return MC_ERR_ARG;
-  if (window >= 3 && (window > t || !(window & 1) || field_in == field_out)) return MC_ERR_ARG;
+  if (window >= 3 && (window > t || field_in == field_out)) return MC_ERR_ARG;
   hipLaunchKernelGGL(field_smooth_center, dim3(1), dim3(256), 0, (hipStream_t)stream, field_in,
                      field_out, t, npatch, window, subtract_mean);
   return mc_check_launch();

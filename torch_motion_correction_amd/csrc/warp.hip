@@ -1169,6 +1169,41 @@ __global__ void warp_pixel_shifts(const float* __restrict__ etab, const int* __r
   }
 }
 
+// get_pixel_shifts at caller-supplied pixel coordinates (the `pixel_grid` argument,
+// correct_motion.py:167-168): coords (n, 2) yx in pixels of an (h, w) frame -> out (n, 2) px.
+// Same fp32 chain as warp_axis_tables with (float)p replaced by the given coordinate; x taps
+// first, then y (ATen's bicubic grid_sample order), reflection padding per tap.
+__global__ void warp_pixel_shifts_at(const float* __restrict__ lattice, int GH, int GW, int h, int w,
+                                     float pixel_spacing, const float* __restrict__ coords, int64_t n,
+                                     float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int tap[2][4];
+  float coef[2][4];
+  for (int axis = 0; axis < 2; ++axis) {
+    const int len = axis == 0 ? h : w, G = axis == 0 ? GH : GW;
+    const float normalized = coords[2 * i + axis] / (float)(len - 1);
+    const float interp = normalized * (float)(G - 1);
+    const float u = grid_chain(interp, (float)G);
+    const float fl = floorf(u);
+    cubic_coeffs(u - fl, coef[axis]);
+    // clamp in float first: a far-away coordinate must not overflow the int conversion
+    const int i0 = (int)fminf(fmaxf(fl, -1.0e9f), 1.0e9f);
+    for (int k = 0; k < 4; ++k) tap[axis][k] = reflect_index(i0 - 1 + k, G);
+  }
+  for (int c = 0; c < 2; ++c) {
+    const float* L = lattice + (int64_t)c * GH * GW;
+    float rowv[4];
+    for (int ky = 0; ky < 4; ++ky) {
+      const float* r = L + (int64_t)tap[0][ky] * GW;
+      rowv[ky] = ((coef[1][0] * r[tap[1][0]] + coef[1][1] * r[tap[1][1]]) + coef[1][2] * r[tap[1][2]]) +
+                 coef[1][3] * r[tap[1][3]];
+    }
+    const float sft = ((coef[0][0] * rowv[0] + coef[0][1] * rowv[1]) + coef[0][2] * rowv[2]) + coef[0][3] * rowv[3];
+    out[2 * i + c] = sft / pixel_spacing;
+  }
+}
+
 // ------------------------------------------------------------------ spline lattice
 // out[c][it][iy][ix] = sum_kt wt sum_ky wy sum_kx wx * data[c][idx_t][idx_y][idx_x]
 // (x innermost, then y, then t -- the separable order of the spline library).
@@ -1316,6 +1351,15 @@ int mc_pixel_shifts(const float* lattice, int GH, int GW, int h, int w, float pi
                      xtap, xcoef, etab);
   hipLaunchKernelGGL(warp_pixel_shifts, dim3((w + 255) / 256, h), dim3(256), 0, s, etab, ytap, ycoef,
                      h, w, GH, pixel_spacing, out);
+  return mc_check_launch();
+}
+
+int mc_pixel_shifts_at(const float* lattice, int GH, int GW, int h, int w, float pixel_spacing,
+                       const float* coords_yx, int64_t n, float* out, void* stream) {
+  if (!lattice || !coords_yx || !out || h < 2 || w < 2 || GH < 1 || GW < 1 || n < 1 || !(pixel_spacing > 0.f))
+    return MC_ERR_ARG;
+  hipLaunchKernelGGL(warp_pixel_shifts_at, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, lattice, GH, GW, h, w, pixel_spacing, coords_yx, n, out);
   return mc_check_launch();
 }
 

@@ -276,17 +276,22 @@ USE_ROW_CHORDS = _os_env_flag("MC_ROW_CHORDS", True)
 
 def global_shifts(img, reference_frame, pixel_spacing, b_factor, frequency_range):
     """Integer-pixel (t,2) shifts of every frame against `reference_frame`
-    (estimate_motion_xc.py:57-123); the reference frame's row is exactly zero."""
+    (estimate_motion_xc.py:57-123); the reference frame's row is exactly zero.
+    `reference_frame` follows the reference's Python indexing (xc.py:101,107): a negative value
+    selects from the end but never equals a loop index, so that frame is NOT skipped (it is
+    correlated with itself); anything outside [-t, t) raises IndexError."""
     t, h, w = img.shape
     dev = img.device
+    ref = _lib.normalize_frame_index(reference_frame, t)
+    skip = int(reference_frame) >= 0
     pl = planmod.get_xc_plan(h, w, pixel_spacing, b_factor, frequency_range, dev)
     S = _global_spectra(img, pl)
-    cur = [f for f in range(t) if f != reference_frame]
+    cur = [f for f in range(t) if not (skip and f == ref)]
     if not cur:
         return torch.zeros((t, 2), dtype=torch.float32, device=dev)
     cur_idx, ref_idx = _cached(
-        ("global_pairs", str(dev), t, reference_frame),
-        lambda: (_i32(cur, dev), _i32([reference_frame] * len(cur), dev)))
+        ("global_pairs", str(dev), t, ref, skip),
+        lambda: (_i32(cur, dev), _i32([ref] * len(cur), dev)))
     # pair p = frame cur[p]: its shift goes to row cur[p] of the (t, 2) table; the reference
     # frame's row is written by nobody and stays exactly zero
     _, shifts, _ = _peaks(S, cur_idx, S, ref_idx, pl, want_nbhd=False, shift_rows=cur_idx, n_shift_rows=t)
@@ -317,7 +322,12 @@ def patch_field(img, stats, pixel_spacing, reference_frame, reference_strategy, 
     gh, gw = len(cy), len(cx)
     npatch = gh * gw
     origin = ((cy[:, None] - p // 2) * w + (cx[None, :] - p // 2)).reshape(-1)  # (npatch,)
-    ref_expo, cur_expo, processed = lattice.mask_schedule(t, reference_strategy, reference_frame)
+    # the memo key is the caller's raw value (a negative key is an entry of its own in the
+    # reference's memo, patch_grid/_patch_grid.py:283-294); the data come from the wrapped index
+    ref_key = int(reference_frame)
+    reference_frame = _lib.normalize_frame_index(ref_key, t)
+    ref_expo, cur_expo, processed, ref_read = lattice.mask_schedule(t, reference_strategy, ref_key,
+                                                                    with_ref_reads=True)
     field = torch.zeros((2, t, gh, gw), dtype=torch.float32, device=dev) if field0 is None \
         else field0.contiguous().clone()
     st = stream_ptr(dev)
@@ -348,7 +358,7 @@ def patch_field(img, stats, pixel_spacing, reference_frame, reference_strategy, 
             exl = [int(cur_expo[f]) + 1 for f in processed]
             off, ex = jobs(processed, exl)
             S_cur = _forward_spectra(img, off, w, ex, pl, stats, min_expo=min(exl))
-            exl = [int(ref_expo[f, reference_frame]) + 1 for f in processed]
+            exl = [int(ref_read[f]) + 1 for f in processed]
             off, ex = jobs([reference_frame] * nproc, exl)
             S_ref = _forward_spectra(img, off, w, ex, pl, stats, min_expo=min(exl))
         pair_idx = torch.arange(nproc * npatch, device=dev, dtype=torch.int32)
@@ -364,9 +374,7 @@ def patch_field(img, stats, pixel_spacing, reference_frame, reference_strategy, 
             window += 1
         window = min(window, t)
         if window < 3:
-            window = 0
-        elif window % 2 == 0:
-            raise ValueError("If mode is 'interp', window_length must be odd (scipy savgol_filter)")
+            window = 0  # (an even window = t for even t < window|1 is what scipy gets, xc.py:506-529)
     out = torch.empty_like(field)
     check(lib.mc_field_smooth_center(ptr(field), ptr(out), t, npatch, window, 1, st),
           "mc_field_smooth_center")
@@ -459,6 +467,20 @@ def pixel_shifts(lattice, h, w, pixel_spacing):
     check(lib.mc_pixel_shifts(ptr(lattice.contiguous()), GH, GW, h, w, float(pixel_spacing),
                               ptr(scratch), ptr(out), stream_ptr(dev)), "mc_pixel_shifts")
     return out
+
+
+def pixel_shifts_at(lattice, h, w, pixel_spacing, coords):
+    """get_pixel_shifts at arbitrary (..., 2) yx pixel coordinates (the reference's `pixel_grid`
+    argument, correct_motion.py:167-168) -> (..., 2) px."""
+    lib = _lib.load()
+    dev = lattice.device
+    _, GH, GW = lattice.shape
+    pts = coords.reshape(-1, 2).contiguous()
+    out = torch.empty_like(pts)
+    if pts.shape[0]:
+        check(lib.mc_pixel_shifts_at(ptr(lattice.contiguous()), GH, GW, h, w, float(pixel_spacing), ptr(pts),
+                                     pts.shape[0], ptr(out), stream_ptr(dev)), "mc_pixel_shifts_at")
+    return out.reshape(coords.shape)
 
 
 # ------------------------------------------------------------------ a19: Fourier shift

@@ -64,8 +64,12 @@ class _Memo:
         return 0
 
 
-def mask_schedule(t: int, reference_strategy: str, reference_frame: int):
-    """Returns (ref_expo, cur_expo, processed):
+def mask_schedule(t: int, reference_strategy: str, reference_frame: int, with_ref_reads: bool = False):
+    """`reference_frame` is the memo KEY as the caller gave it: the reference's memo is a dict keyed
+    by the raw Python int, so -1 and t-1 are two entries (gathered from the same frame) with
+    exponents of their own, and a negative key never equals a loop index (no frame is skipped).
+    Returns (ref_expo, cur_expo, processed) and, `with_ref_reads`, also ref_read[f] = exponent of
+    the reference entry when frame f read it (middle_frame; -1 = not read):
     ref_expo[f][o]  exponent of entry o when it was read to build frame f's reference
                     (-1 = not read);
     cur_expo[f]     exponent of entry f when it was read as the current frame;
@@ -74,6 +78,8 @@ def mask_schedule(t: int, reference_strategy: str, reference_frame: int):
     ref_expo = np.full((t, t), -1, dtype=np.int64)
     cur_expo = np.full((t,), -1, dtype=np.int64)
     processed = []
+    ref_read = np.full((t,), -1, dtype=np.int64)
+    ref_col = reference_frame % t if t > 0 else 0
     # tensors handed out by the memo stay alive (and keep being mutated) while the
     # caller holds them even if the memo evicted them: model them as boxes.
     boxes: dict[int, list[int]] = {}
@@ -95,7 +101,8 @@ def mask_schedule(t: int, reference_strategy: str, reference_frame: int):
             if f == reference_frame:
                 continue
             rbox = fetch(reference_frame)
-            ref_expo[f, reference_frame] = rbox[0]
+            ref_expo[f, ref_col] = rbox[0]
+            ref_read[f] = rbox[0]
         elif reference_strategy == "mean_except_current":
             rbox = None
             for o in range(t):
@@ -109,6 +116,8 @@ def mask_schedule(t: int, reference_strategy: str, reference_frame: int):
             rbox[0] += 1  # ref_patches *= mask on the memo's own tensor
         cbox[0] += 1  # frame_patches *= mask on the memo's own tensor
         processed.append(f)
+    if with_ref_reads:
+        return ref_expo, cur_expo, processed, ref_read
     return ref_expo, cur_expo, processed
 
 

@@ -17,7 +17,7 @@ from typing import Callable, Iterable, Optional
 import torch
 
 from . import engine
-from ._lib import require_gpu
+from ._lib import device_scope, require_gpu
 
 
 @dataclass
@@ -71,37 +71,43 @@ class MoviePipeline:
         and return its result; it runs with the warp stream current."""
         dev = self.device
         call = around_warp if around_warp is not None else (lambda fn: fn())
+        # every enqueue happens with the pipeline's GPU as the current HIP device (libmcorr launches
+        # on the current device); the scope is left again before control returns to the caller
         if not self.overlap:
             for img in movies:
-                img = self._check(img)
-                field = self._estimate(img)
-                frames, total = call(lambda: self._correct(img, field))
-                yield MovieResult(field, total, frames)
-            return
-        caller = torch.cuda.current_stream(dev)
-        start = torch.cuda.Event()
-        start.record(caller)
-        self._s_est.wait_event(start)
-        self._s_warp.wait_event(start)
-        try:
-            for img in movies:
-                img = self._check(img)
-                img.record_stream(self._s_est)
-                img.record_stream(self._s_warp)
-                with torch.cuda.stream(self._s_est):
+                with device_scope(dev):
+                    img = self._check(img)
                     field = self._estimate(img)
-                    ready = torch.cuda.Event()
-                    ready.record(self._s_est)
-                with torch.cuda.stream(self._s_warp):
-                    self._s_warp.wait_event(ready)
-                    field.record_stream(self._s_warp)
                     frames, total = call(lambda: self._correct(img, field))
                 yield MovieResult(field, total, frames)
+            return
+        with device_scope(dev):
+            caller = torch.cuda.current_stream(dev)
+            start = torch.cuda.Event()
+            start.record(caller)
+            self._s_est.wait_event(start)
+            self._s_warp.wait_event(start)
+        try:
+            for img in movies:
+                with device_scope(dev):
+                    img = self._check(img)
+                    img.record_stream(self._s_est)
+                    img.record_stream(self._s_warp)
+                    with torch.cuda.stream(self._s_est):
+                        field = self._estimate(img)
+                        ready = torch.cuda.Event()
+                        ready.record(self._s_est)
+                    with torch.cuda.stream(self._s_warp):
+                        self._s_warp.wait_event(ready)
+                        field.record_stream(self._s_warp)
+                        frames, total = call(lambda: self._correct(img, field))
+                yield MovieResult(field, total, frames)
         finally:
-            for s in (self._s_est, self._s_warp):
-                done = torch.cuda.Event()
-                done.record(s)
-                caller.wait_event(done)
+            with device_scope(dev):
+                for s in (self._s_est, self._s_warp):
+                    done = torch.cuda.Event()
+                    done.record(s)
+                    caller.wait_event(done)
 
     def run(self, movies: Iterable[torch.Tensor],
             around_warp: Optional[Callable[[Callable[[], object]], object]] = None) -> list[MovieResult]:
