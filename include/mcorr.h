@@ -237,8 +237,8 @@ int mc_spline_lattice(const float* data, int c, int nt, int nh, int nw, const in
  * correct_motion.py:132-185), then bicubic/border resample of the frame at
  * pixel + shift/pixel_spacing with zero outside (_correct_frame + sample_image_2d,
  * correct_motion.py:81-129).  scratch: mc_warp_scratch_bytes() bytes, 16-byte aligned.
- * out_frames (nframes*h*w) and/or out_sum (h*w, accumulated with +=; caller zeroes)
- * may be NULL (not both). */
+ * out_frames (nframes*h*w) and/or out_sum (h*w, OVERWRITTEN with the sum over the frames: the
+ * caller need not clear it) may be NULL (not both). */
 int mc_warp_scratch_bytes(int nframes, int h, int w, int GH, int GW, int64_t* bytes /*host*/);
 int mc_warp_frames(const float* frames, int nframes, int h, int w, const float* lattice, int GH,
                    int GW, float pixel_spacing, float* scratch, float* out_frames, float* out_sum,

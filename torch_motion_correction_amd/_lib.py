@@ -98,12 +98,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("MCORR_LIB", LIB_PATH)  # experiments: an A/B build from scripts/build_variant.sh
+    if not os.path.exists(path):
         raise McorrError(
             f"{LIB_PATH} not found: build it with `python -m torch_motion_correction_amd._build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback."
         )
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = argtypes

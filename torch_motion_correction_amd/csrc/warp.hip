@@ -339,7 +339,7 @@ __global__ __launch_bounds__(WARP_TX* WARP_TY) void warp_main(WarpArgs a) {
     for (int r = 0; r < WARP_ROWS; ++r) {
       if (r == 1 && !two) break;
       float* o = a.out_sum + (int64_t)(ya + r) * w + x0;
-      for (int k = 0; k < WARP_PX && x0 + k < w; ++k) o[k] += acc[r][k];
+      for (int k = 0; k < WARP_PX && x0 + k < w; ++k) o[k] = acc[r][k];  // this thread owns the pixel for all frames
     }
   }
 }
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES, RIGID_MINW) void warp_rig
       const int yo = y0 + ro;
       if (yo < h) {
         float* dst = a.out_sum + (int64_t)yo * w + x0;
-        for (int k = 0; k < 4 && x0 + k < w; ++k) dst[k] += acc[ro][k];
+        for (int k = 0; k < 4 && x0 + k < w; ++k) dst[k] = acc[ro][k];  // one block owns the tile's sum
       }
     }
   }
@@ -627,14 +627,13 @@ __global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES, RIGID_MINW) void warp_rig
 #define RD_QUADS_PAD (((RIGID_NQ + 63) / 64) * 64)  // DMA granule: 64 lanes x 16 B
 typedef __attribute__((address_space(3))) void* lds_vptr;
 
-template <bool WRITE_FRAMES, bool WRITE_SUM, bool FULL>
-__device__ __forceinline__ void rigid_strip_dma(const RigidArgs& a, const float4* tile, int f,
-                                                int y0, int x0, int wave, int lane, float wyv,
+template <bool WRITE_FRAMES, bool WRITE_SUM, bool FULL, int QUADS>
+__device__ __forceinline__ void rigid_strip_dma(const RigidArgs& a, const float4* wrow, int f,
+                                                int y0, int x0, float wyv,
                                                 const float (&wx)[5][4],
                                                 float (&acc)[RIGID_ROWS][4]) {
   const int h = a.h, w = a.w;
-  const float4* wrow = tile + (wave * RIGID_ROWS) * RIGID_QUADS + lane;
-  // FULL: the whole 32 x 256 tile lies inside the image -> no per-row predicates, the strip is
+  // FULL: the whole tile lies inside the image -> no per-row predicates, the strip is
   // one basic block and the scheduler can run the LDS reads ahead of the arithmetic
   float* orow = WRITE_FRAMES ? a.out_frames + (int64_t)f * h * w + (int64_t)y0 * w + x0 : nullptr;
   float H[5][4];
@@ -644,7 +643,7 @@ __device__ __forceinline__ void rigid_strip_dma(const RigidArgs& a, const float4
 #define RIGID_SB 2
 #endif
     if (RIGID_SB > 0 && (rr % (RIGID_SB > 0 ? RIGID_SB : 1)) == 0) __builtin_amdgcn_sched_barrier(0);
-    const float4 q0 = wrow[rr * RIGID_QUADS], q1 = wrow[rr * RIGID_QUADS + 1];
+    const float4 q0 = wrow[rr * QUADS], q1 = wrow[rr * QUADS + 1];
     const float e[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
     float* Hn = H[rr % 5];
 #pragma unroll
@@ -674,12 +673,21 @@ __device__ __forceinline__ void rigid_strip_dma(const RigidArgs& a, const float4
   }
 }
 
-template <bool WRITE_FRAMES, bool WRITE_SUM, int NBUF>
-__global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES, NBUF == 1 ? 4 : 2)
+// Tile geometry: WX waves side by side (256 columns each) x WY waves down (8 rows each), i.e. a
+// tile of 256 WX x 8 WY output pixels per workgroup of 64 WX WY threads.  (1, 4) is the 256 x 32
+// tile of round 1; wider tiles make every row piece a workgroup touches longer (1 KiB per 256
+// columns: fewer partial 128-byte lines at the two ends, longer runs inside a DRAM page).
+template <bool WRITE_FRAMES, bool WRITE_SUM, int NBUF, int WX, int WY>
+__global__ __launch_bounds__(RIGID_LANES* WX* WY, NBUF == 1 ? 4 : 2)  // 16 (8) waves per CU whatever the tile
 void warp_rigid_dma(RigidArgs a) {
+  constexpr int NWAVES = WX * WY;
+  constexpr int TROWS = WY * RIGID_ROWS + 4;       // input rows per tile
+  constexpr int QUADS = WX * RIGID_LANES + 4;      // float4 columns per tile row
+  constexpr int NQ = TROWS * QUADS;
+  constexpr int QUADS_PAD = ((NQ + 63) / 64) * 64;  // DMA granule: 64 lanes x 16 B
   extern __shared__ __attribute__((aligned(16))) char smem_rd[];
   float4* const b0 = reinterpret_cast<float4*>(smem_rd);
-  float4* const b1 = NBUF == 2 ? b0 + RD_QUADS_PAD : b0;
+  float4* const b1 = NBUF == 2 ? b0 + QUADS_PAD : b0;
   const int nt = a.tiles_x * a.tiles_y;
   const int b = blockIdx.x;
   int tile = b;
@@ -688,18 +696,19 @@ void warp_rigid_dma(RigidArgs a) {
   const int h = a.h, w = a.w;
   const int lane = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int wvx = wave % WX, wvy = wave / WX;
   const int tid = wave * RIGID_LANES + lane;
-  const int xt = txi * (RIGID_LANES * 4);
-  const int yt = tyi * (RIGID_WAVES * RIGID_ROWS);
-  const int x0 = xt + lane * 4;
-  const int y0 = yt + wave * RIGID_ROWS;
+  const int xt = txi * (RIGID_LANES * 4 * WX);
+  const int yt = tyi * (WY * RIGID_ROWS);
+  const int x0 = xt + wvx * (RIGID_LANES * 4) + lane * 4;
+  const int y0 = yt + wvy * RIGID_ROWS;
   const int64_t hw = (int64_t)h * w;
   float acc[RIGID_ROWS][4];
 #pragma unroll
   for (int r = 0; r < RIGID_ROWS; ++r)
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[r][k] = 0.f;
-  const bool full_tile = yt + RIGID_WAVES * RIGID_ROWS <= h && xt + RIGID_LANES * 4 <= w;
+  const bool full_tile = yt + WY * RIGID_ROWS <= h && xt + RIGID_LANES * 4 * WX <= w;
   const int f_lo = a.frames_in_grid ? (int)blockIdx.y * a.frames_in_grid : 0;
   const int f_hi = a.frames_in_grid ? min(f_lo + a.frames_in_grid, a.nframes) : a.nframes;
 
@@ -708,10 +717,10 @@ void warp_rigid_dma(RigidArgs a) {
     const float* fr = a.frames + (int64_t)f * hw;
     const int Sy = a.S[2 * f], Sx = a.S[2 * f + 1];
     const int ax = xt + Sx - 1;  // any multiple of 4 BYTES: the global side of the DMA needs no more
-    for (int i = wave; i < RD_QUADS_PAD / 64; i += RIGID_WAVES) {
+    for (int i = wave; i < QUADS_PAD / 64; i += NWAVES) {
       int q = i * 64 + lane;
-      q = q < RIGID_NQ ? q : RIGID_NQ - 1;  // tail lanes re-load the last quad into the pad
-      const int tr = q / RIGID_QUADS, qc = q - tr * RIGID_QUADS;
+      q = q < NQ ? q : NQ - 1;  // tail lanes re-load the last quad into the pad
+      const int tr = q / QUADS, qc = q - tr * QUADS;
       int r = yt + Sy - 1 + tr;
       r = r < 0 ? 0 : (r > h - 1 ? h - 1 : r);
       int c = ax + 4 * qc;
@@ -725,11 +734,11 @@ void warp_rigid_dma(RigidArgs a) {
   auto patch = [&](int f, float4* t4) {
     const int Sy = a.S[2 * f], Sx = a.S[2 * f + 1];
     const int ax = xt + Sx - 1;
-    if (ax >= 0 && ax + 4 * RIGID_QUADS <= w) return false;
+    if (ax >= 0 && ax + 4 * QUADS <= w) return false;
     const float* fr = a.frames + (int64_t)f * hw;
     float* t = reinterpret_cast<float*>(t4);
-    for (int q = tid; q < RIGID_NQ; q += RIGID_LANES * RIGID_WAVES) {
-      const int tr = q / RIGID_QUADS, qc = q - tr * RIGID_QUADS;
+    for (int q = tid; q < NQ; q += RIGID_LANES * NWAVES) {
+      const int tr = q / QUADS, qc = q - tr * QUADS;
       const int s0 = ax + 4 * qc;
       if (s0 >= 0 && s0 <= w - 4) continue;
       int r = yt + Sy - 1 + tr;
@@ -758,6 +767,7 @@ void warp_rigid_dma(RigidArgs a) {
       W5[j][0] = t.x; W5[j][1] = t.y; W5[j][2] = t.z; W5[j][3] = t.w;
     }
   };
+  const int strip = (wvy * RIGID_ROWS) * QUADS + wvx * RIGID_LANES + lane;  // this lane's first quad
 
   load_weights(f_lo, wx, wyv);
   dma(f_lo, b0);
@@ -773,12 +783,12 @@ void warp_rigid_dma(RigidArgs a) {
       dma(f + 1, cur ? b0 : b1);
       load_weights(f + 1, wxn, wyvn);
     }
-    const float4* t = cur ? b1 : b0;
-    if (full_tile) rigid_strip_dma<WRITE_FRAMES, WRITE_SUM, true>(a, t, f, y0, x0, wave, lane, wyv, wx, acc);
-    else rigid_strip_dma<WRITE_FRAMES, WRITE_SUM, false>(a, t, f, y0, x0, wave, lane, wyv, wx, acc);
+    const float4* t = (cur ? b1 : b0) + strip;
+    if (full_tile) rigid_strip_dma<WRITE_FRAMES, WRITE_SUM, true, QUADS>(a, t, f, y0, x0, wyv, wx, acc);
+    else rigid_strip_dma<WRITE_FRAMES, WRITE_SUM, false, QUADS>(a, t, f, y0, x0, wyv, wx, acc);
     if (f + 1 < f_hi) {
       if constexpr (NBUF == 1) {
-        // single buffer, 4 workgroups per CU: other workgroups cover this one's latency,
+        // single buffer, several workgroups per CU: other workgroups cover this one's latency,
         // so nothing is double-buffered here (registers are the scarce resource)
         __syncthreads();  // everyone must be done reading before the tile is refilled
         dma(f + 1, b0);
@@ -805,9 +815,15 @@ void warp_rigid_dma(RigidArgs a) {
     for (int ro = 0; ro < RIGID_ROWS; ++ro) {
       const int yo = y0 + ro;
       if (yo < h) {
+        // one block owns its tile's sum over all frames: a plain store (no zero fill, no read-back);
+        // w % 4 == 0 on this path, so the quad is 16-byte aligned whenever out_sum is
         float* dst = a.out_sum + (int64_t)yo * w + x0;
+        if ((((uintptr_t)a.out_sum) & 15) == 0) {
+          *reinterpret_cast<float4*>(dst) = make_float4(acc[ro][0], acc[ro][1], acc[ro][2], acc[ro][3]);
+        } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) dst[k] += acc[ro][k];
+          for (int k = 0; k < 4; ++k) dst[k] = acc[ro][k];
+        }
       }
     }
   }
@@ -1085,7 +1101,7 @@ __global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES, 2) void warp_field(FieldA
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int x = xt + lane + 64 * k;
-        if (x < w) a.out_sum[(int64_t)y * w + x] += acc[r][k];
+        if (x < w) a.out_sum[(int64_t)y * w + x] = acc[r][k];  // warp_field_slow adds its tile-frames afterwards
       }
     }
   }
@@ -1392,8 +1408,24 @@ int mc_warp_rigid_phase(const float* frames, int nframes, int h, int w, const fl
   RigidArgs a;
   a.frames = frames; a.nframes = nframes; a.h = h; a.w = w; a.S = S; a.Wy = Wy; a.Wx = Wx;
   a.out_frames = out_frames; a.out_sum = out_sum;
-  a.tiles_x = (w + RIGID_LANES * 4 - 1) / (RIGID_LANES * 4);
-  a.tiles_y = (h + RIGID_WAVES * RIGID_ROWS - 1) / (RIGID_WAVES * RIGID_ROWS);
+  static int use_dma = -1, geom = -1, nbuf = -1;
+  if (use_dma < 0) {
+    const char* v = getenv("MC_RIGID_DMA");
+    use_dma = v ? atoi(v) : 1;
+    v = getenv("MC_RIGID_GEOM");  // "WXxWY" as two digits, e.g. 14 = 256 x 32 tiles, 24 = 512 x 32
+    // default 24: 512 x 32 tiles, 2 workgroups of 8 waves per CU.  The kernel runs at the box's
+    // mixed read+write ceiling (~5 TB/s of L2<->fabric traffic, scripts/mall_probe.py), so its time
+    // is its bytes: the window over-fetch (halo rows x partial 128-byte lines at both ends of every
+    // row piece) is 1.33x for 256 x 32 tiles and 1.23x for 512 x 32 (measured 1.32 -> 1.23 ms)
+    geom = v ? atoi(v) : 24;
+    v = getenv("MC_RIGID_NBUF");
+    nbuf = v ? atoi(v) : 1;  // single buffer: 3-4 workgroups/CU beat 2 double-buffered ones
+  }
+  const bool dma_ok = use_dma && (w % 4 == 0) && ((((uintptr_t)frames) & 15) == 0) &&
+                      (!out_frames || ((((uintptr_t)out_frames) & 15) == 0));
+  const int WX = dma_ok ? geom / 10 : 1, WY = dma_ok ? geom % 10 : RIGID_WAVES;
+  a.tiles_x = (w + RIGID_LANES * 4 * WX - 1) / (RIGID_LANES * 4 * WX);
+  a.tiles_y = (h + WY * RIGID_ROWS - 1) / (WY * RIGID_ROWS);
   // Without the fused sum every frame is its own block: blocks are dispatched frame-major, so the
   // resident ones always work on neighbouring tiles of ONE frame and halo rows / shared 128-byte
   // lines hit in L2 (FETCH_SIZE 2.76 GB for 2.68 GB of frames).  With the sum a block keeps its
@@ -1401,31 +1433,40 @@ int mc_warp_rigid_phase(const float* frames, int nframes, int h, int w, const fl
   // halos miss (3.7 GB) -- measured 0.97 ms vs 1.28 ms at 40 x 4096^2.
   a.frames_in_grid = out_sum ? 0 : 1;
   dim3 grid(a.tiles_x * a.tiles_y, a.frames_in_grid ? (nframes + a.frames_in_grid - 1) / a.frames_in_grid : 1),
-      block(RIGID_LANES, RIGID_WAVES);
-  static int use_dma = -1;
-  if (use_dma < 0) {
-    const char* v = getenv("MC_RIGID_DMA");
-    use_dma = v ? atoi(v) : 1;
-  }
-  const bool dma_ok = use_dma && (w % 4 == 0) && ((((uintptr_t)frames) & 15) == 0) &&
-                      (!out_frames || ((((uintptr_t)out_frames) & 15) == 0));
+      block(RIGID_LANES, WX * WY);
   if (dma_ok) {
-    static int nbuf = -1;
-    if (nbuf < 0) {
-      const char* v = getenv("MC_RIGID_NBUF");
-      nbuf = v ? atoi(v) : 1;  // single buffer: 3-4 workgroups/CU beat 2 double-buffered ones
-    }
-    const size_t lds = (size_t)(nbuf == 1 ? 1 : 2) * RD_QUADS_PAD * 16;
-#define MC_RD_LAUNCH(F, S)                                                                        \
-  do {                                                                                            \
-    auto k = nbuf == 1 ? warp_rigid_dma<F, S, 1> : warp_rigid_dma<F, S, 2>;                        \
+#define MC_RD_GO(F, S, NB, GX, GY)                                                                  \
+  do {                                                                                              \
+    auto k = warp_rigid_dma<F, S, NB, GX, GY>;                                                       \
+    const size_t lds = (size_t)NB * ((((GY * RIGID_ROWS + 4) * (GX * RIGID_LANES + 4)) + 63) / 64) * 64 * 16; \
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL(k, grid, block, lds, s, a);                                                \
+    hipLaunchKernelGGL(k, grid, block, lds, s, a);                                                  \
+  } while (0)
+#define MC_RD_GEOM(F, S, NB)                                   \
+  do {                                                         \
+    if (geom == 14) MC_RD_GO(F, S, NB, 1, 4);                  \
+    else if (geom == 22) MC_RD_GO(F, S, NB, 2, 2);             \
+    else if (geom == 24) MC_RD_GO(F, S, NB, 2, 4);             \
+    else if (geom == 41) MC_RD_GO(F, S, NB, 4, 1);             \
+    else if (geom == 42) MC_RD_GO(F, S, NB, 4, 2);             \
+    else if (geom == 18) MC_RD_GO(F, S, NB, 1, 8);             \
+    else if (geom == 16) MC_RD_GO(F, S, NB, 1, 6);             \
+    else if (geom == 12) MC_RD_GO(F, S, NB, 1, 2);             \
+    else if (geom == 28) MC_RD_GO(F, S, NB, 2, 8);             \
+    else if (geom == 26) MC_RD_GO(F, S, NB, 2, 6);             \
+    else return MC_ERR_UNSUPPORTED;                                   \
+  } while (0)
+#define MC_RD_LAUNCH(F, S)                                     \
+  do {                                                         \
+    if (nbuf == 1) MC_RD_GEOM(F, S, 1);                        \
+    else MC_RD_GEOM(F, S, 2);                                  \
   } while (0)
     if (out_frames && out_sum) MC_RD_LAUNCH(true, true);
     else if (out_frames) MC_RD_LAUNCH(true, false);
     else MC_RD_LAUNCH(false, true);
 #undef MC_RD_LAUNCH
+#undef MC_RD_GEOM
+#undef MC_RD_GO
     return mc_check_launch();
   }
   if (out_frames && out_sum) hipLaunchKernelGGL((warp_rigid<true, true>), grid, block, 0, s, a);

@@ -432,7 +432,7 @@ def warp(img, lattices, pixel_spacing, want_frames=True, want_sum=False, rigid=F
     dev = img.device
     _, _, GH, GW = lattices.shape
     frames = torch.empty_like(img) if want_frames else None
-    total = torch.zeros((h, w), dtype=torch.float32, device=dev) if want_sum else None
+    total = torch.empty((h, w), dtype=torch.float32, device=dev) if want_sum else None  # the kernels store it
     nbytes = C.c_int64(0)
     if rigid:
         shifts_px = (lattices[:, :, 0, 0] / pixel_spacing).contiguous()  # shifts_angstroms / ps
