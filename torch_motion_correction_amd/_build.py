@@ -19,6 +19,10 @@ LIB_PATH = os.path.join(PKG_DIR, "libmcorr.so")
 SOURCES = ["plan_stats.hip", "xc_fft.hip", "field_post.hip", "warp.hip", "local_motion.hip", "polyphase.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+# warp.hip: the SLP vectoriser turns the per-pixel coordinate chain into v_pk_* instructions fed by
+# ~1300 v_mov_b32 per kernel and 90 more VGPRs (warp_field 215 -> 160); packed fp32 issues at half
+# the scalar rate on gfx950, so nothing is gained for it
+EXTRA_FLAGS = {"warp.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(target: str, deps: list[str]) -> bool:
@@ -38,7 +42,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         srcp = os.path.join(CSRC, src)
         if force or _stale(obj, [srcp] + headers):
-            cmd = [HIPCC, *FLAGS, f"-I{INCLUDE}", f"-I{CSRC}", "-c", srcp, "-o", obj]
+            cmd = [HIPCC, *FLAGS, *EXTRA_FLAGS.get(src, []), f"-I{INCLUDE}", f"-I{CSRC}", "-c", srcp, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)

@@ -1107,6 +1107,581 @@ __global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES, 2) void warp_field(FieldA
   }
 }
 
+// ------------------------------------------------------------------ general warp, second version
+// Same tiling, window DMA and per-pixel chain as warp_field, rebuilt around what limits it -- VALU
+// issue and the number of window bytes:
+//  * the window margin follows the field: mg = ceil(3.8 rho + 1.05) per axis and tile-frame (2 for
+//    the smooth fields of real movies) instead of the fixed 6, lanes outside the needed window
+//    issue no DMA (window bytes 1.6x -> 1.3x of the tile);
+//  * 3 workgroups per CU (one 52 KB window each), so a workgroup's DMA wait hides under two others;
+//  * tile-frames whose window lies inside the image (all but the frame's rim) take a body without
+//    the zero-outside test and without index clamps;
+//  * cubic-convolution weights in factored form: c0 = A t u^2, c3 = A u t^2, c1 = 1 - t^2 ((A+3) -
+//    (A+2) t), c2 likewise in u = 1 - t (11 instead of 17 operations per axis; the same polynomials
+//    as ATen's Horner forms, values equal to ~1e-7).
+#ifndef GW2_MINW
+#define GW2_MINW 3
+#endif
+#ifndef GW2_ILP
+#define GW2_ILP 1
+#endif
+#pragma clang fp contract(fast)
+__device__ __forceinline__ void cubic_coeffs_factored(float t, float c[4]) {
+  const float A = -0.75f;
+  const float u = 1.f - t;
+  const float atu = (A * t) * u;
+  c[0] = atu * u;
+  c[3] = atu * t;
+  c[1] = 1.f - (t * t) * ((A + 3.f) - (A + 2.f) * t);
+  c[2] = 1.f - (u * u) * ((A + 3.f) - (A + 2.f) * u);
+}
+#pragma clang fp contract(off)
+
+template <bool WRITE_FRAMES, bool WRITE_SUM, bool UNIT_PS>
+__global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES, GW2_MINW) void warp_field2(FieldArgs fa) {
+  const WarpArgs& a = fa.w;
+  extern __shared__ __attribute__((aligned(16))) char smem_gw[];
+  float4* const tile4 = reinterpret_cast<float4*>(smem_gw);
+  float* const tile = reinterpret_cast<float*>(smem_gw);
+  __shared__ int s_ytap[RIGID_WAVES * RIGID_ROWS][4];
+  __shared__ float s_ycoef[RIGID_WAVES * RIGID_ROWS][4];
+  const int nt = a.tiles_x * a.tiles_y;
+  const int b = blockIdx.x;
+  int tl = b;
+  if ((nt & 7) == 0) tl = (b & 7) * (nt >> 3) + (b >> 3);
+  const int tyi = tl / a.tiles_x, txi = tl - tyi * a.tiles_x;
+  const int h = a.h, w = a.w;
+  const float fh = (float)h, fw = (float)w;
+  const int lane = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int tid = wave * RIGID_LANES + lane;
+  const int xt = txi * (RIGID_LANES * 4);
+  const int yt = tyi * (RIGID_WAVES * RIGID_ROWS);
+  const int y0 = yt + wave * RIGID_ROWS;
+  const int64_t hw = (int64_t)h * w;
+  if (tid < RIGID_WAVES * RIGID_ROWS) {  // frame-invariant per-row lattice taps of this tile
+    const int y = yt + tid < h ? yt + tid : h - 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      s_ytap[tid][k] = a.ytap[4 * y + k];
+      s_ycoef[tid][k] = a.ycoef[4 * y + k];
+    }
+  }
+  // lattice footprint of the tile (frame-invariant): node rows [R0,R1], node columns [C0,C1]
+  int R0, R1, C0, C1;
+  {
+    int lo = 0x7fffffff, hi = -1;
+    if (lane < RIGID_WAVES * RIGID_ROWS) {
+      const int y = yt + lane < h ? yt + lane : h - 1;
+      for (int k = 0; k < 4; ++k) {
+        const int v = a.ytap[4 * y + k];
+        lo = v < lo ? v : lo;
+        hi = v > hi ? v : hi;
+      }
+    }
+    R0 = wave_min_i(lo);
+    R1 = wave_max_i(hi);
+    lo = 0x7fffffff;
+    hi = -1;
+    for (int k = 0; k < 4; ++k) {
+      const int x = xt + lane + 64 * k;
+      const int xs = x < w ? x : w - 1;
+      for (int j = 0; j < 4; ++j) {
+        const int v = fa.xtap[4 * xs + j];
+        lo = v < lo ? v : lo;
+        hi = v > hi ? v : hi;
+      }
+    }
+    C0 = wave_min_i(lo);
+    C1 = wave_max_i(hi);
+  }
+  const int yc = (yt + 16 < h) ? yt + 16 : h - 1;  // centre pixel of the tile (clipped to the image)
+  const int xc = (xt + 128 < w) ? xt + 128 : w - 1;
+  const int4 ytc = *reinterpret_cast<const int4*>(a.ytap + 4 * yc);
+  const float4 ycc = *reinterpret_cast<const float4*>(a.ycoef + 4 * yc);
+  const bool whole_tile = yt + RIGID_WAVES * RIGID_ROWS <= h && xt + RIGID_LANES * 4 <= w;
+  float acc[RIGID_ROWS][4];
+#pragma unroll
+  for (int r = 0; r < RIGID_ROWS; ++r)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[r][k] = 0.f;
+  __syncthreads();
+
+  for (int f = 0; f < a.nframes; ++f) {
+    const float* fr = a.frames + (int64_t)f * hw;
+    const float* E = a.etab + (int64_t)f * 2 * a.GH * w;
+    const int64_t chs = (int64_t)a.GH * w;  // channel stride of E
+    // 0. regularity -> window margins: range of the lattice nodes that can influence this tile.
+    // |shift - shift_centre| <= 3.8 rho (bicubic: sum|w| < 1.9 in 2-D, twice for the centre's own
+    // deviation); taps span [-1,+2] around floor(); coordinate rounding adds < 0.01 px.
+    int mgy, mgx;
+    {
+      const float* L = fa.lattice + (int64_t)f * 2 * a.GH * fa.GW;
+      const int ncol = C1 - C0 + 1, nnode = (R1 - R0 + 1) * ncol;
+      float lo_y = 3.0e38f, hi_y = -3.0e38f, lo_x = 3.0e38f, hi_x = -3.0e38f;
+      for (int i = lane; i < nnode; i += RIGID_LANES) {
+        const int R = R0 + i / ncol, Cc = C0 + i % ncol;
+        const float vy = L[(int64_t)R * fa.GW + Cc], vx = L[(int64_t)(a.GH + R) * fa.GW + Cc];
+        lo_y = fminf(lo_y, vy); hi_y = fmaxf(hi_y, vy);
+        lo_x = fminf(lo_x, vx); hi_x = fmaxf(hi_x, vx);
+      }
+      const float ry = 0.5f * (wave_max_f(hi_y) - wave_min_f(lo_y)) / a.pixel_spacing;
+      const float rx = 0.5f * (wave_max_f(hi_x) - wave_min_f(lo_x)) / a.pixel_spacing;
+      const float ny = 3.8f * ry + 1.05f, nx = 3.8f * rx + 1.05f;
+      // NaNs fail the comparison and go to the slow kernel (workgroup-uniform: every wave
+      // computed the same numbers)
+      if (!((ny <= (float)GW_MG) && (nx <= (float)GW_MG))) {
+        if (tid == 0) fa.flags[(int64_t)f * nt + tl] = 1;
+        continue;
+      }
+      mgy = __builtin_amdgcn_readfirstlane((int)ceilf(ny));
+      mgx = __builtin_amdgcn_readfirstlane((int)ceilf(nx));
+    }
+    const int nrows = RIGID_WAVES * RIGID_ROWS + 3 + 2 * mgy;          // <= GW_ROWS
+    int nq = (RIGID_LANES * 4 + 6 + 2 * mgx + 3) / 4;                    // <= GW_QUADS
+    nq = nq < GW_QUADS ? nq : GW_QUADS;
+    // 1. window origin from the shift at the tile centre (identical in every lane)
+    int wy0, ax;
+    {
+      const float* Ec = E + xc;
+      float sy = dot4(ycc, Ec[(int64_t)ytc.x * w], Ec[(int64_t)ytc.y * w], Ec[(int64_t)ytc.z * w],
+                      Ec[(int64_t)ytc.w * w]);
+      float sx = dot4(ycc, Ec[chs + (int64_t)ytc.x * w], Ec[chs + (int64_t)ytc.y * w],
+                      Ec[chs + (int64_t)ytc.z * w], Ec[chs + (int64_t)ytc.w * w]);
+      if (!UNIT_PS) {
+        sy = div_invariant(sy, a.pixel_spacing);
+        sx = div_invariant(sx, a.pixel_spacing);
+      }
+      const float lim = 4.f * (fh + fw);
+      const float dy = fminf(fmaxf(floorf(grid_chain((float)yc + sy, fh)) - (float)yc, -lim), lim);
+      const float dx = fminf(fmaxf(floorf(grid_chain((float)xc + sx, fw)) - (float)xc, -lim), lim);
+      wy0 = __builtin_amdgcn_readfirstlane(yt + (int)dy - 1 - mgy);
+      ax = __builtin_amdgcn_readfirstlane((xt + (int)dx - 1 - mgx) & ~3);
+    }
+    // 2. window -> LDS (the previous frame's reads are behind the barrier at the loop's end); the
+    // LDS image keeps the fixed row stride, lanes outside the needed rows / quads issue nothing
+    for (int i = wave; i < GW_QUADS_PAD / 64; i += RIGID_WAVES) {
+      const int q = i * 64 + lane;
+      const int tr = q / GW_QUADS, qc = q - tr * GW_QUADS;
+      if (tr < nrows && qc < nq) {
+        int r = wy0 + tr;
+        r = r < 0 ? 0 : (r > h - 1 ? h - 1 : r);
+        int c = ax + 4 * qc;
+        c = c < 0 ? 0 : (c > w - 4 ? w - 4 : c);
+        __builtin_amdgcn_global_load_lds(fr + (int64_t)r * w + c, (lds_vptr)(tile4 + i * 64), 16, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const bool interior = whole_tile && wy0 >= 0 && wy0 + nrows <= h && ax >= 0 && ax + 4 * nq <= w;
+    if (ax < 0 || ax + 4 * nq > w) {  // border padding: clipped columns (edge tiles only)
+      for (int i = tid; i < nrows * GW_STRIDE; i += RIGID_LANES * RIGID_WAVES) {
+        const int tr = i / GW_STRIDE, e = i - tr * GW_STRIDE;
+        const int c = ax + e;
+        if (e < 4 * nq && (c < 0 || c > w - 1)) {
+          const int cc = c < 0 ? 0 : w - 1;
+          int qsrc = (cc & ~3) - ax;
+          qsrc = qsrc < 0 ? 0 : (qsrc > 4 * nq - 4 ? 4 * nq - 4 : qsrc);
+          tile[tr * GW_STRIDE + e] = tile[tr * GW_STRIDE + qsrc + (cc & 3)];
+        }
+      }
+      __syncthreads();
+    }
+    // 3. pixels
+    int4 ycache = make_int4(-1, -1, -1, -1);
+    float ey[4][4], ex[4][4];  // [lattice tap][pixel k]
+    const int oy = 1 + wy0, ox = 1 + ax;
+#pragma unroll
+    for (int r = 0; r < RIGID_ROWS; ++r) {
+      const int y = y0 + r;
+      if (y >= h) break;
+      // the row tables are frame-invariant: without an opaque index LICM lifts all 8 rows' taps
+      // and weights out of the frame loop (64 VGPRs for the whole kernel)
+      int row = wave * RIGID_ROWS + r;
+      asm volatile("" : "+s"(row));
+      const int4 yt4 = make_int4(s_ytap[row][0], s_ytap[row][1], s_ytap[row][2], s_ytap[row][3]);
+      const float4 yc4 = make_float4(s_ycoef[row][0], s_ycoef[row][1], s_ycoef[row][2], s_ycoef[row][3]);
+      if (yt4.x != ycache.x || yt4.y != ycache.y || yt4.z != ycache.z || yt4.w != ycache.w) {
+        ycache = yt4;  // wave-uniform: depends on y only
+        const int rows4[4] = {yt4.x, yt4.y, yt4.z, yt4.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int x = xt + lane + 64 * k;
+            const int xs = x < w ? x : w - 1;
+            ey[i][k] = E[(int64_t)rows4[i] * w + xs];
+            ex[i][k] = E[chs + (int64_t)rows4[i] * w + xs];
+          }
+      }
+      float* orow = WRITE_FRAMES ? a.out_frames + (int64_t)f * hw + (int64_t)y * w + xt + lane : nullptr;
+      if (interior) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (k % GW2_ILP == 0) __builtin_amdgcn_sched_barrier(0);  // GW2_ILP pixels in flight (register pressure)
+          float sy = dot4(yc4, ey[0][k], ey[1][k], ey[2][k], ey[3][k]);
+          float sx = dot4(yc4, ex[0][k], ex[1][k], ex[2][k], ex[3][k]);
+          if (!UNIT_PS) {
+            sy = div_invariant(sy, a.pixel_spacing);
+            sx = div_invariant(sx, a.pixel_spacing);
+          }
+          const float uy = grid_chain((float)y + sy, fh), ux = grid_chain((float)(xt + lane + 64 * k) + sx, fw);
+          const float fy = floorf(uy), fx = floorf(ux);
+          float wy[4], wx[4];
+          cubic_coeffs_factored(uy - fy, wy);
+          cubic_coeffs_factored(ux - fx, wx);
+          const float* t0 = tile + ((int)fy - oy) * GW_STRIDE + ((int)fx - ox);
+          float rowv[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float* t = t0 + i * GW_STRIDE;
+            rowv[i] = gw_dot4(wx, t[0], t[1], t[2], t[3]);
+          }
+          const float o = gw_dot4(wy, rowv[0], rowv[1], rowv[2], rowv[3]);
+          if (WRITE_FRAMES) orow[64 * k] = o;
+          if (WRITE_SUM) acc[r][k] += o;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          __builtin_amdgcn_sched_barrier(0);
+          const int x = xt + lane + 64 * k;
+          if (x >= w) continue;
+          float sy = dot4(yc4, ey[0][k], ey[1][k], ey[2][k], ey[3][k]);
+          float sx = dot4(yc4, ex[0][k], ex[1][k], ex[2][k], ex[3][k]);
+          if (!UNIT_PS) {
+            sy = div_invariant(sy, a.pixel_spacing);
+            sx = div_invariant(sx, a.pixel_spacing);
+          }
+          const float cy = (float)y + sy, cx = (float)x + sx;
+          const bool inside = (cy >= 0.f) && (cy <= fh - 1.f) && (cx >= 0.f) && (cx <= fw - 1.f);
+          const float uy = grid_chain(cy, fh), ux = grid_chain(cx, fw);
+          const float fy = floorf(uy), fx = floorf(ux);
+          float wy[4], wx[4];
+          cubic_coeffs_factored(uy - fy, wy);
+          cubic_coeffs_factored(ux - fx, wx);
+          // in range by the regularity test; the clamp only keeps a garbage coordinate from
+          // reading outside the LDS tile
+          int ly = (int)fy - oy, lx = (int)fx - ox;
+          ly = ly < 0 ? 0 : (ly > GW_ROWS - 4 ? GW_ROWS - 4 : ly);
+          lx = lx < 0 ? 0 : (lx > GW_STRIDE - 4 ? GW_STRIDE - 4 : lx);
+          const float* t0 = tile + ly * GW_STRIDE + lx;
+          float rowv[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float* t = t0 + i * GW_STRIDE;
+            rowv[i] = gw_dot4(wx, t[0], t[1], t[2], t[3]);
+          }
+          float o = gw_dot4(wy, rowv[0], rowv[1], rowv[2], rowv[3]);
+          o = inside ? o : 0.f;
+          if (WRITE_FRAMES) orow[64 * k] = o;
+          if (WRITE_SUM) acc[r][k] += o;
+        }
+      }
+    }
+    __syncthreads();  // everyone is done with the tile before the next frame overwrites it
+  }
+  if (WRITE_SUM) {
+#pragma unroll
+    for (int r = 0; r < RIGID_ROWS; ++r) {
+      const int y = y0 + r;
+      if (y >= h) break;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int x = xt + lane + 64 * k;
+        if (x < w) a.out_sum[(int64_t)y * w + x] = acc[r][k];  // warp_field_slow adds its tile-frames afterwards
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ general warp, third version
+// What the counters said about warp_field / warp_field2 (40 x 4092 x 5760, sum only, 3.0 ms): 88
+// VALU instructions per pixel, almost all on the 2-cycle pipe, i.e. 1.1 ms of issue -- but a wave
+// issued only every ~10 cycles (the per-pixel chain is one long dependency, 8 cycles from a result
+// to its use, plus an LDS round trip per pixel) and 3 waves per SIMD were all the registers (32
+// partial sums + 32 cached lattice values per lane) and the LDS (one window per workgroup) allowed;
+// 37 % of the wave cycles were waits.  So: thread-level parallelism instead of registers.
+//  * One workgroup of 16 waves per CU and tile; a wave owns TWO pixel rows (8 partial sums per
+//    lane, ~70 VGPRs): 4 waves per SIMD.
+//  * The window of frame f+1 is DMA'd into a second LDS buffer while frame f is computed (one
+//    barrier per frame, no exposed DMA wait).
+//  * The x-upsampled lattice rows the tile needs (E, <= 6 rows x 256 columns x 2 channels) are
+//    DMA'd into LDS with the window instead of being cached in registers.
+//  * Window origin, margins and the regularity verdict of every (tile, frame) come from a small
+//    plan kernel, so no wave ever waits for a dependent global load inside the frame loop.
+#define GW3_WAVES 16
+#define GW3_RW (RIGID_WAVES * RIGID_ROWS / GW3_WAVES)  // pixel rows per wave (2)
+#define GW3_EROWS 6                                     // lattice rows staged per tile
+#define GW3_PLAN_MAX 128                                // frames whose plan entries are kept in LDS
+
+// plan[f * nt + tile] = {wy0, ax, mgy | mgx << 8 | irregular << 16, first staged lattice row R0}
+__global__ __launch_bounds__(64) void warp_field_plan(FieldArgs fa, int unit_ps, int4* __restrict__ plan) {
+  const WarpArgs& a = fa.w;
+  const int nt = a.tiles_x * a.tiles_y;
+  const int tl = blockIdx.x, f = blockIdx.y;
+  const int tyi = tl / a.tiles_x, txi = tl - tyi * a.tiles_x;
+  const int h = a.h, w = a.w;
+  const float fh = (float)h, fw = (float)w;
+  const int lane = threadIdx.x;
+  const int xt = txi * (RIGID_LANES * 4), yt = tyi * (RIGID_WAVES * RIGID_ROWS);
+  int R0, R1, C0, C1;
+  {
+    int lo = 0x7fffffff, hi = -1;
+    if (lane < RIGID_WAVES * RIGID_ROWS) {
+      const int y = yt + lane < h ? yt + lane : h - 1;
+      for (int k = 0; k < 4; ++k) {
+        const int v = a.ytap[4 * y + k];
+        lo = v < lo ? v : lo;
+        hi = v > hi ? v : hi;
+      }
+    }
+    R0 = wave_min_i(lo);
+    R1 = wave_max_i(hi);
+    lo = 0x7fffffff;
+    hi = -1;
+    for (int k = 0; k < 4; ++k) {
+      const int x = xt + lane + 64 * k;
+      const int xs = x < w ? x : w - 1;
+      for (int j = 0; j < 4; ++j) {
+        const int v = fa.xtap[4 * xs + j];
+        lo = v < lo ? v : lo;
+        hi = v > hi ? v : hi;
+      }
+    }
+    C0 = wave_min_i(lo);
+    C1 = wave_max_i(hi);
+  }
+  const int yc = (yt + 16 < h) ? yt + 16 : h - 1;
+  const int xc = (xt + 128 < w) ? xt + 128 : w - 1;
+  const int4 ytc = *reinterpret_cast<const int4*>(a.ytap + 4 * yc);
+  const float4 ycc = *reinterpret_cast<const float4*>(a.ycoef + 4 * yc);
+  const float* E = a.etab + (int64_t)f * 2 * a.GH * w;
+  const int64_t chs = (int64_t)a.GH * w;
+  const float* L = fa.lattice + (int64_t)f * 2 * a.GH * fa.GW;
+  const int ncol = C1 - C0 + 1, nnode = (R1 - R0 + 1) * ncol;
+  float lo_y = 3.0e38f, hi_y = -3.0e38f, lo_x = 3.0e38f, hi_x = -3.0e38f;
+  for (int i = lane; i < nnode; i += RIGID_LANES) {
+    const int R = R0 + i / ncol, Cc = C0 + i % ncol;
+    const float vy = L[(int64_t)R * fa.GW + Cc], vx = L[(int64_t)(a.GH + R) * fa.GW + Cc];
+    lo_y = fminf(lo_y, vy); hi_y = fmaxf(hi_y, vy);
+    lo_x = fminf(lo_x, vx); hi_x = fmaxf(hi_x, vx);
+  }
+  const float ry = 0.5f * (wave_max_f(hi_y) - wave_min_f(lo_y)) / a.pixel_spacing;
+  const float rx = 0.5f * (wave_max_f(hi_x) - wave_min_f(lo_x)) / a.pixel_spacing;
+  const float ny = 3.8f * ry + 1.05f, nx = 3.8f * rx + 1.05f;
+  const bool regular = (ny <= (float)GW_MG) && (nx <= (float)GW_MG) && (R1 - R0 + 1 <= GW3_EROWS);
+  int4 out = make_int4(0, 0, 1 << 16, R0);
+  if (regular) {
+    const int mgy = (int)ceilf(ny), mgx = (int)ceilf(nx);
+    const float* Ec = E + xc;
+    float sy = dot4(ycc, Ec[(int64_t)ytc.x * w], Ec[(int64_t)ytc.y * w], Ec[(int64_t)ytc.z * w],
+                    Ec[(int64_t)ytc.w * w]);
+    float sx = dot4(ycc, Ec[chs + (int64_t)ytc.x * w], Ec[chs + (int64_t)ytc.y * w],
+                    Ec[chs + (int64_t)ytc.z * w], Ec[chs + (int64_t)ytc.w * w]);
+    if (!unit_ps) {
+      sy = div_invariant(sy, a.pixel_spacing);
+      sx = div_invariant(sx, a.pixel_spacing);
+    }
+    const float lim = 4.f * (fh + fw);
+    const float dy = fminf(fmaxf(floorf(grid_chain((float)yc + sy, fh)) - (float)yc, -lim), lim);
+    const float dx = fminf(fmaxf(floorf(grid_chain((float)xc + sx, fw)) - (float)xc, -lim), lim);
+    out = make_int4(yt + (int)dy - 1 - mgy, (xt + (int)dx - 1 - mgx) & ~3, mgy | (mgx << 8), R0);
+  }
+  if (lane == 0) {
+    plan[(int64_t)f * nt + tl] = out;
+    if (!regular) fa.flags[(int64_t)f * nt + tl] = 1;
+  }
+}
+
+template <bool WRITE_FRAMES, bool WRITE_SUM, bool UNIT_PS>
+__global__ __launch_bounds__(RIGID_LANES* GW3_WAVES, 4) void warp_field3(FieldArgs fa, const int4* __restrict__ plan) {
+  const WarpArgs& a = fa.w;
+  extern __shared__ __attribute__((aligned(16))) char smem_gw[];
+  // [window 0][window 1][E 0][E 1]
+  auto win_of = [&](int bi) { return reinterpret_cast<float4*>(smem_gw) + bi * GW_QUADS_PAD; };
+  auto est_of = [&](int bi) {
+    return reinterpret_cast<float*>(smem_gw + 2 * GW_QUADS_PAD * 16) + bi * (2 * GW3_EROWS * 256);
+  };
+  __shared__ int s_ytap[RIGID_WAVES * RIGID_ROWS][4];
+  __shared__ float s_ycoef[RIGID_WAVES * RIGID_ROWS][4];
+  const int nt = a.tiles_x * a.tiles_y;
+  const int b = blockIdx.x;
+  int tl = b;
+  if ((nt & 7) == 0) tl = (b & 7) * (nt >> 3) + (b >> 3);
+  const int tyi = tl / a.tiles_x, txi = tl - tyi * a.tiles_x;
+  const int h = a.h, w = a.w;
+  const float fh = (float)h, fw = (float)w;
+  const int lane = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int tid = wave * RIGID_LANES + lane;
+  const int xt = txi * (RIGID_LANES * 4);
+  const int yt = tyi * (RIGID_WAVES * RIGID_ROWS);
+  const int y0 = yt + wave * GW3_RW;
+  const int64_t hw = (int64_t)h * w;
+  const int64_t chs = (int64_t)a.GH * w;
+  if (tid < RIGID_WAVES * RIGID_ROWS) {
+    const int y = yt + tid < h ? yt + tid : h - 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      s_ytap[tid][k] = a.ytap[4 * y + k];
+      s_ycoef[tid][k] = a.ycoef[4 * y + k];
+    }
+  }
+  const bool whole_tile = yt + RIGID_WAVES * RIGID_ROWS <= h && xt + RIGID_LANES * 4 <= w;
+  float acc[GW3_RW][4];
+#pragma unroll
+  for (int r = 0; r < GW3_RW; ++r)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[r][k] = 0.f;
+
+  // the tile's plan entries of all frames go to LDS once: a per-frame global load would put its
+  // latency in front of every frame's DMA
+  __shared__ int4 s_plan[GW3_PLAN_MAX];
+  for (int i = tid; i < a.nframes && i < GW3_PLAN_MAX; i += RIGID_LANES * GW3_WAVES) s_plan[i] = plan[(int64_t)i * nt + tl];
+  __syncthreads();
+  auto fetch_plan = [&](int f) {
+    const int4 p = f < GW3_PLAN_MAX ? s_plan[f] : plan[(int64_t)f * nt + tl];
+    return make_int4(__builtin_amdgcn_readfirstlane(p.x), __builtin_amdgcn_readfirstlane(p.y),
+                     __builtin_amdgcn_readfirstlane(p.z), __builtin_amdgcn_readfirstlane(p.w));
+  };
+  // window + lattice rows of frame f -> LDS buffer `bi` (nothing for an irregular tile-frame)
+  auto dma = [&](int f, const int4 p, int bi) {
+    if (p.z >> 16) return;
+    const float* fr = a.frames + (int64_t)f * hw;
+    const int mgy = p.z & 255, mgx = (p.z >> 8) & 255;
+    const int nrows = RIGID_WAVES * RIGID_ROWS + 3 + 2 * mgy;
+    int nq = (RIGID_LANES * 4 + 6 + 2 * mgx + 3) / 4;
+    nq = nq < GW_QUADS ? nq : GW_QUADS;
+    for (int i = wave; i < GW_QUADS_PAD / 64; i += GW3_WAVES) {
+      const int q = i * 64 + lane;
+      const int tr = q / GW_QUADS, qc = q - tr * GW_QUADS;
+      if (tr < nrows && qc < nq) {
+        int r = p.x + tr;
+        r = r < 0 ? 0 : (r > h - 1 ? h - 1 : r);
+        int c = p.y + 4 * qc;
+        c = c < 0 ? 0 : (c > w - 4 ? w - 4 : c);
+        __builtin_amdgcn_global_load_lds(fr + (int64_t)r * w + c, (lds_vptr)(win_of(bi) + i * 64), 16, 0, 0);
+      }
+    }
+    if (wave < 2 * GW3_EROWS) {  // one 1 KiB piece per (channel, lattice row)
+      const int ch = wave / GW3_EROWS, er = wave - ch * GW3_EROWS;
+      int R = p.w + er;
+      R = R > a.GH - 1 ? a.GH - 1 : R;
+      int c = xt + 4 * lane;
+      c = c > w - 4 ? w - 4 : c;  // columns beyond the image are never used
+      const float* src = a.etab + (int64_t)f * 2 * chs + ch * chs + (int64_t)R * w + c;
+      __builtin_amdgcn_global_load_lds(src, (lds_vptr)(est_of(bi) + (ch * GW3_EROWS + er) * 256), 16, 0, 0);
+    }
+  };
+
+  int4 pc = fetch_plan(0);
+  dma(0, pc, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int f = 0; f < a.nframes; ++f) {
+    const int bi = f & 1;
+    int4 pn = pc;
+    if (f + 1 < a.nframes) {
+      pn = fetch_plan(f + 1);
+      dma(f + 1, pn, bi ^ 1);  // lands under this frame's arithmetic
+    }
+    if (!(pc.z >> 16)) {
+      const int wy0 = pc.x, ax = pc.y, mgy = pc.z & 255, mgx = (pc.z >> 8) & 255, R0 = pc.w;
+      const int nrows = RIGID_WAVES * RIGID_ROWS + 3 + 2 * mgy;
+      int nq = (RIGID_LANES * 4 + 6 + 2 * mgx + 3) / 4;
+      nq = nq < GW_QUADS ? nq : GW_QUADS;
+      float* const tile = reinterpret_cast<float*>(win_of(bi));
+      const float* const es = est_of(bi);
+      if (ax < 0 || ax + 4 * nq > w) {  // border padding: clipped columns (edge tiles only)
+        for (int i = tid; i < nrows * GW_STRIDE; i += RIGID_LANES * GW3_WAVES) {
+          const int tr = i / GW_STRIDE, e = i - tr * GW_STRIDE;
+          const int c = ax + e;
+          if (e < 4 * nq && (c < 0 || c > w - 1)) {
+            const int cc = c < 0 ? 0 : w - 1;
+            int qsrc = (cc & ~3) - ax;
+            qsrc = qsrc < 0 ? 0 : (qsrc > 4 * nq - 4 ? 4 * nq - 4 : qsrc);
+            tile[tr * GW_STRIDE + e] = tile[tr * GW_STRIDE + qsrc + (cc & 3)];
+          }
+        }
+        __syncthreads();
+      }
+      const bool interior = whole_tile && wy0 >= 0 && wy0 + nrows <= h && ax >= 0 && ax + 4 * nq <= w;
+      const int oy = 1 + wy0, ox = 1 + ax;
+      // One pixel at a time.  (Measured alternatives, same results, none faster: the wave's two rows
+      // statement by statement for two independent chains per lane, 3.2 ms instead of 2.96; the same
+      // on 2-float vectors, i.e. v_pk_* instructions, 3.3 ms.  The kernel is bound by VALU issue at
+      // ~1.6-2 ns per instruction -- three-source instructions whose operands share a VGPR bank take
+      // 4 cycles instead of 2, scripts/ubench/valu_banks.hip -- not by dependency latency.)
+#pragma unroll
+      for (int r = 0; r < GW3_RW; ++r) {
+        const int y = y0 + r;
+        if (y >= h) break;
+        const int row = wave * GW3_RW + r;
+        const float4 yc4 = make_float4(s_ycoef[row][0], s_ycoef[row][1], s_ycoef[row][2], s_ycoef[row][3]);
+        const float* e0 = es + (s_ytap[row][0] - R0) * 256 + lane;
+        const float* e1 = es + (s_ytap[row][1] - R0) * 256 + lane;
+        const float* e2 = es + (s_ytap[row][2] - R0) * 256 + lane;
+        const float* e3 = es + (s_ytap[row][3] - R0) * 256 + lane;
+        float* orow = WRITE_FRAMES ? a.out_frames + (int64_t)f * hw + (int64_t)y * w + xt + lane : nullptr;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int x = xt + lane + 64 * k;
+          if (!interior && x >= w) continue;
+          float sy = dot4(yc4, e0[64 * k], e1[64 * k], e2[64 * k], e3[64 * k]);
+          float sx = dot4(yc4, e0[64 * k + GW3_EROWS * 256], e1[64 * k + GW3_EROWS * 256],
+                          e2[64 * k + GW3_EROWS * 256], e3[64 * k + GW3_EROWS * 256]);
+          if (!UNIT_PS) {
+            sy = div_invariant(sy, a.pixel_spacing);
+            sx = div_invariant(sx, a.pixel_spacing);
+          }
+          const float cy = (float)y + sy, cx = (float)x + sx;
+          const float uy = grid_chain(cy, fh), ux = grid_chain(cx, fw);
+          const float fy = floorf(uy), fx = floorf(ux);
+          float wy[4], wx[4];
+          cubic_coeffs_factored(uy - fy, wy);
+          cubic_coeffs_factored(ux - fx, wx);
+          int ly = (int)fy - oy, lx = (int)fx - ox;
+          bool inside = true;
+          if (!interior) {
+            inside = (cy >= 0.f) && (cy <= fh - 1.f) && (cx >= 0.f) && (cx <= fw - 1.f);
+            // in range by the regularity test; the clamp only keeps a garbage coordinate from
+            // reading outside the LDS tile
+            ly = ly < 0 ? 0 : (ly > GW_ROWS - 4 ? GW_ROWS - 4 : ly);
+            lx = lx < 0 ? 0 : (lx > GW_STRIDE - 4 ? GW_STRIDE - 4 : lx);
+          }
+          const float* t0 = tile + ly * GW_STRIDE + lx;
+          float rowv[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float* t = t0 + i * GW_STRIDE;
+            rowv[i] = gw_dot4(wx, t[0], t[1], t[2], t[3]);
+          }
+          float o = gw_dot4(wy, rowv[0], rowv[1], rowv[2], rowv[3]);
+          o = inside ? o : 0.f;
+          if (WRITE_FRAMES) orow[64 * k] = o;
+          if (WRITE_SUM) acc[r][k] += o;
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA of f+1 (and this frame's stores)
+    __syncthreads();  // buffer bi is free again, buffer bi^1 is complete
+    pc = pn;
+  }
+  if (WRITE_SUM) {
+#pragma unroll
+    for (int r = 0; r < GW3_RW; ++r) {
+      const int y = y0 + r;
+      if (y >= h) break;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int x = xt + lane + 64 * k;
+        if (x < w) a.out_sum[(int64_t)y * w + x] = acc[r][k];  // warp_field_slow adds its tile-frames afterwards
+      }
+    }
+  }
+}
+
 // Tile-frames warp_field flagged as irregular: generic per-pixel gathers from global
 // memory (border padding by clipping every tap coordinate).  One workgroup per tile, so
 // the += on out_sum cannot race.
@@ -1278,8 +1853,9 @@ int mc_spline_lattice(const float* data, int c, int nt, int nh, int nw, const in
 
 int mc_warp_scratch_bytes(int nframes, int h, int w, int GH, int GW, int64_t* bytes) {
   if (!bytes || nframes < 1 || h < 2 || w < 2 || GH < 1 || GW < 1) return MC_ERR_ARG;
-  // etab floats + (ytap,ycoef,xtap,xcoef) + one flag byte per (frame, 256x32 tile)
-  *bytes = (etab_floats(nframes, GH, w) + 8 * (int64_t)(h + w)) * 4 + field_flag_bytes(nframes, h, w);
+  // etab floats + (ytap,ycoef,xtap,xcoef) + one flag byte and one 16-byte plan entry per
+  // (frame, 256x32 tile)
+  *bytes = (etab_floats(nframes, GH, w) + 8 * (int64_t)(h + w)) * 4 + 17 * field_flag_bytes(nframes, h, w);
   return MC_OK;
 }
 
@@ -1322,10 +1898,47 @@ int mc_warp_frames(const float* frames, int nframes, int h, int w, const float* 
     if (e != hipSuccess) return (int)e;
     dim3 grid(a.tiles_x * a.tiles_y), block(RIGID_LANES, RIGID_WAVES);
     const size_t lds = (size_t)GW_QUADS_PAD * 16;
+    static int field_version = -1;
+    if (field_version < 0) {
+      const char* v = getenv("MC_WARP_FIELD");
+      field_version = v ? atoi(v) : 3;
+    }
+    // version 3 stages <= GW3_EROWS lattice rows per tile: 32 pixel rows must span <= 1.5 lattice
+    // cells (always for the reference's 10 nodes per patch; not for a per-pixel lattice)
+    if (field_version == 3 && (int64_t)32 * (GH - 1) * 2 <= (int64_t)3 * (h - 1)) {
+      int4* plan = reinterpret_cast<int4*>(fa.flags + field_flag_bytes(nframes, h, w));
+      hipLaunchKernelGGL(warp_field_plan, dim3(a.tiles_x * a.tiles_y, nframes), dim3(64), 0, s, fa, unit ? 1 : 0, plan);
+      const size_t lds3 = (size_t)2 * GW_QUADS_PAD * 16 + (size_t)2 * 2 * GW3_EROWS * 256 * 4;
+      dim3 block3(RIGID_LANES, GW3_WAVES);
+#define MC_GW3_GO(F, S, U)                                                                        \
+  do {                                                                                            \
+    auto k = warp_field3<F, S, U>;                                                                \
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3); \
+    hipLaunchKernelGGL(k, grid, block3, lds3, s, fa, (const int4*)plan);                          \
+  } while (0)
+#define MC_GW3_LAUNCH(F, S)          \
+  do {                               \
+    if (unit) MC_GW3_GO(F, S, true); \
+    else MC_GW3_GO(F, S, false);     \
+  } while (0)
+      if (out_frames && out_sum) MC_GW3_LAUNCH(true, true);
+      else if (out_frames) MC_GW3_LAUNCH(true, false);
+      else MC_GW3_LAUNCH(false, true);
+#undef MC_GW3_LAUNCH
+#undef MC_GW3_GO
+      if (unit) hipLaunchKernelGGL((warp_field_slow<true>), grid, block, 0, s, fa, out_frames ? 1 : 0, out_sum ? 1 : 0);
+      else hipLaunchKernelGGL((warp_field_slow<false>), grid, block, 0, s, fa, out_frames ? 1 : 0, out_sum ? 1 : 0);
+      return mc_check_launch();
+    }
 #define MC_GW_LAUNCH(F, S)                                                                  \
   do {                                                                                      \
-    if (unit) hipLaunchKernelGGL((warp_field<F, S, true>), grid, block, lds, s, fa);        \
-    else hipLaunchKernelGGL((warp_field<F, S, false>), grid, block, lds, s, fa);            \
+    if (field_version == 1) {  /* (version 3 falls back to 2 for dense lattices) */          \
+      if (unit) hipLaunchKernelGGL((warp_field<F, S, true>), grid, block, lds, s, fa);      \
+      else hipLaunchKernelGGL((warp_field<F, S, false>), grid, block, lds, s, fa);          \
+    } else {                                                                                \
+      if (unit) hipLaunchKernelGGL((warp_field2<F, S, true>), grid, block, lds, s, fa);     \
+      else hipLaunchKernelGGL((warp_field2<F, S, false>), grid, block, lds, s, fa);         \
+    }                                                                                       \
   } while (0)
     if (out_frames && out_sum) MC_GW_LAUNCH(true, true);
     else if (out_frames) MC_GW_LAUNCH(true, false);
