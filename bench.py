@@ -9,7 +9,7 @@ One process per GPU; movies are independent, so ranks never exchange data (weak
 scaling: one stack per rank per step).  torch.distributed (RCCL) is used only for the
 start/stop barrier and the max-over-ranks of the elapsed time.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (warp_main):
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (warp_rigid_dma):
 algorithmic bytes per launch = 8 B/pixel/frame x 40 frames (each frame read once and
 written once) over its mean duration, measured with HIP events on
 the launch stream around each launch inside the timed region.  `cpu_baseline` is the
@@ -51,11 +51,32 @@ def synth_stack(t, h, w, seed, device, noise=1.0, pad=64):
     return stack, dy, dx
 
 
+def synth_local_motion_stack(mc, t, h, w, gh, gw, seed, device, amp=2.0, noise=0.5):
+    """Input for the local-motion workload: one texture seen through a smooth, small
+    deformation (|shift| <= amp px) that grows with time -- what the patch estimator is made for
+    (the rigid-drift stack above is not: its frames are several pixels apart, the correlation with
+    the mean of the other frames has one peak per frame and the patch field is meaningless).
+    The frames are generated with the product's own warp; this is a timing workload, parity of
+    the same construction is tested against the oracle in tests/test_gpu_parity.py."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    base = torch.randn(h, w, generator=g, device=device)
+    base = (base + torch.roll(base, 1, 0) + torch.roll(base, 1, 1) + torch.roll(base, (1, 1), (0, 1))) / 2
+    tt = torch.linspace(-1, 1, t)[:, None, None]
+    yy = torch.linspace(-1, 1, gh)[None, :, None]
+    xx = torch.linspace(-1, 1, gw)[None, None, :]
+    true = torch.stack([amp * tt * torch.sin(2.0 * yy + xx), amp * tt * torch.cos(1.5 * xx - yy)]).to(device)
+    stack = torch.empty((t, h, w), dtype=torch.float32, device=device)
+    for f in range(t):
+        stack[f] = mc.correct_motion(base[None], -true[:, f:f + 1], 1.0, grid_type="bspline")[0]
+        stack[f] += noise * torch.randn(h, w, generator=g, device=device)
+    return stack, float(base.std())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=40)
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -88,6 +109,9 @@ def main():
 
     t, h, w = args.frames, args.size, args.size
     stack, dy, dx = synth_stack(t, h, w, 1234 + rank, dev)
+    # consecutive steps alternate between two different stacks with the same drift (same recipe,
+    # another seed): no step finds its own input still in a cache
+    stack_b, _, _ = synth_stack(t, h, w, 4321 + rank, dev)
     ref = t // 2
     expect = torch.tensor([[dy[f] - dy[ref], dx[f] - dx[ref]] for f in range(t)], dtype=torch.float32)
 
@@ -112,7 +136,7 @@ def main():
         last = None
         engine.RIGID_KERNEL_HOOK = timed_warp if record else None  # events around warp_rigid_dma alone
         try:
-            for res in pipe.iterate([stack] * n):
+            for res in pipe.iterate([stack, stack_b][i % 2] for i in range(n)):
                 last = res  # earlier results are dropped: their memory is reused by the next step
         finally:
             engine.RIGID_KERNEL_HOOK = None
@@ -187,7 +211,7 @@ def main():
             del out
             torch.cuda.empty_cache()
             t3, h3, w3 = 40, 4092, 5760
-            st3, _, _ = synth_stack(t3, h3, w3, 7, dev)
+            st3, tex_std = synth_local_motion_stack(mc, t3, h3, w3, 6, 10, 7, dev)
             times = []
             for _ in range(3):
                 torch.cuda.synchronize()
@@ -204,6 +228,9 @@ def main():
                             f"({f3.shape[2]}x{f3.shape[3]} patches) + B-spline warp + frame sum",
                 "estimate_ms": 1e3 * est, "correct_sum_ms": 1e3 * cor, "frames_per_s": t3 / (est + cor),
                 "sum_finite": bool(torch.isfinite(s3).all()),
+                # aligned frames add coherently: 1.0 = the sum's spread is t x the texture's
+                "sum_coherence": float(s3[64:-64, 64:-64].std()) / (t3 * tex_std),
+                "input": "one texture through a smooth time-dependent deformation (|shift| <= 2 px) + noise",
             }
             # the optimiser-based estimator on the same movie: 100 Adam iterations refining the
             # patch field's lattice (estimate_local_motion; second call = plans and torch.optim warm)
@@ -255,6 +282,9 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "warp_rigid_dma", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                # `traffic` = HBM bytes per launch from the rocprofv3 PMC passes committed under
+                # profiles/ (FETCH_SIZE x 2 + WRITE_SIZE, separate passes): NOT measured in this run
+                "traffic_source": "profiles/warp_traffic.json (rocprofv3 --pmc, committed)" if traffic else None,
                 "ms_per_launch": warp_ms, "algorithmic_bytes_per_launch": alg_bytes,
                 # extras: the kernel alone on the chip, and the whole step against SURVEY 8d's
                 # compulsory 12 B/pixel/frame (frame read by the estimator, read + written by the warp)

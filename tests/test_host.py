@@ -468,3 +468,62 @@ def test_mask_schedule_with_a_negative_reference_key():
     assert ref_read.tolist() == [0, 1, 2, 3, 4] and cur_expo.tolist() == [0, 0, 0, 0, 0]
     ref_expo, cur_expo, processed, ref_read = lattice.mask_schedule(5, "middle_frame", 4, with_ref_reads=True)
     assert processed == [0, 1, 2, 3] and ref_read.tolist() == [0, 1, 2, 3, -1]
+
+
+class _FakeResult:
+    def __init__(self, field, total):
+        self.field, self.total = field, total
+
+
+class _FakePipeline:
+    """CPU stand-in with MoviePipeline's iterate() contract: the 'field' of a movie is its
+    per-frame mean (so the gathered table can be checked exactly), the 'sum' its frame sum."""
+
+    def iterate(self, movies):
+        for m in movies:
+            f = torch.stack([m.mean(dim=(1, 2)), -m.mean(dim=(1, 2))])[:, :, None, None]
+            yield _FakeResult(f, m.sum(0))
+
+
+def _sharded_rank_main(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        loaded = []
+
+        def load(i):
+            loaded.append(i)
+            return torch.full((3, 4, 5), float(i)) + torch.arange(3.0)[:, None, None]
+
+        fields, sums = multi_gpu.motion_correct_movies_sharded(
+            list(range(7)), rank, world, 1.0, load=load, pipeline_factory=_FakePipeline)
+        q.put((rank, loaded, {k: v.tolist() for k, v in fields.items()}, sorted(sums)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_driver_two_ranks_gloo():
+    """motion_correct_movies_sharded: every rank touches only its round-robin shard, the fields of
+    ALL movies come back on every rank, the sums stay with their rank (7 movies over 2 ranks)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sharded_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, l0, f0, s0), (r1, l1, f1, s1) = results
+    assert l0 == [0, 2, 4, 6] and l1 == [1, 3, 5] and s0 == l0 and s1 == l1
+    assert f0 == f1 and sorted(f0) == list(range(7))
+    for i in range(7):
+        assert f0[i][0] == [[[float(i)]], [[float(i) + 1]], [[float(i) + 2]]]
+
+
+def test_sharded_driver_single_rank_needs_no_process_group():
+    fields, sums = multi_gpu.motion_correct_movies_sharded(
+        [torch.ones(2, 3, 3) * k for k in range(3)], 0, 1, 1.0, pipeline_factory=_FakePipeline)
+    assert sorted(fields) == [0, 1, 2] and sorted(sums) == [0, 1, 2]
+    assert float(sums[2].sum()) == 2 * 2 * 9

@@ -24,6 +24,7 @@ from .api import (  # noqa: F401
 from ._lib import McorrError  # noqa: F401
 from .data_io import read_deformation_field_from_csv, write_deformation_field_to_csv  # noqa: F401
 from .optimization_state import OptimizationState, OptimizationTracker  # noqa: F401
+from .multi_gpu import motion_correct_movies_sharded  # noqa: F401
 from .pipeline import MoviePipeline, MovieResult, motion_correct_movies  # noqa: F401
 
 __all__ = [
@@ -49,6 +50,7 @@ __all__ = [
     "write_deformation_field_to_csv",
     "read_deformation_field_from_csv",
     "motion_correct_movies",
+    "motion_correct_movies_sharded",
     "MoviePipeline",
     "MovieResult",
 ]
