@@ -51,11 +51,21 @@ int mc_circle_mask(float* mask, int* halfw, int h, int w, float radius, float sm
 int mc_xc_filter(float* filt, const mc_xc_geom* geom, float low, float high, float b_factor,
                  float pixel_size, void* stream);
 
+/* storage types of frame data (the values of mc_condition_movie's `kind`) */
+#define MC_STORE_U8 0
+#define MC_STORE_I16 1
+#define MC_STORE_F16 2
+#define MC_STORE_F32 3
+
 /* ---- a2: normalize_image statistics (utils.py:49-84) ---------------------------- */
 /* mean and unbiased std of stack[:, hl:hu, wl:wu] over all t frames jointly.
  * acc: 2 doubles of scratch; out3 = {mean, 1/std, std} as floats. */
 int mc_central_box_stats(const float* stack, int t, int h, int w, int hl, int hu, int wl, int wu,
                          double* acc, float* out3, void* stream);
+/* The same over frames in their storage type (MC_STORE_F32 / MC_STORE_F16): statistics of the
+ * fp32 up-cast, read straight from the fp16 bytes. */
+int mc_central_box_stats_t(const void* stack, int storage, int t, int h, int w, int hl, int hu, int wl,
+                           int wu, double* acc, float* out3, void* stream);
 /* dst = (src - mean) * (1/std), n elements (normalize_image's elementwise pass). */
 int mc_normalize(const float* src, float* dst, int64_t n, const float* mean_rstd, void* stream);
 
@@ -102,6 +112,13 @@ int mc_xc_rows_forward_dual(const float* src, const int64_t* job_off, int64_t ro
                             const float* mean_rstd, void* T1a, void* T1b, const void* tw_row,
                             int njobs, const mc_xc_geom* geom, const int* row_chord /* NULL or as in
                             mc_xc_rows_forward_stats */, void* stream);
+/* The same reading the samples in their storage type (MC_STORE_F32 or MC_STORE_F16; job_off and
+ * row_stride in elements): an fp16 movie is transformed without an fp32 copy of it.  Results are
+ * those of the fp32 up-cast (the reference cannot run Half on the CPU at all). */
+int mc_xc_rows_forward_dual_t(const void* src, int storage, const int64_t* job_off, int64_t row_stride,
+                              const int* expo_a, const int* expo_b, const float* mask,
+                              const float* mean_rstd, void* T1a, void* T1b, const void* tw_row,
+                              int njobs, const mc_xc_geom* geom, const int* row_chord, void* stream);
 
 /* Column-transform engine of K2 / the near-window K3: 0 = automatic (H == 4096 with at most
  * 512 kept rows at either end of the spectrum -> register-resident radix-16 transform;
@@ -243,6 +260,13 @@ int mc_warp_scratch_bytes(int nframes, int h, int w, int GH, int GW, int64_t* by
 int mc_warp_frames(const float* frames, int nframes, int h, int w, const float* lattice, int GH,
                    int GW, float pixel_spacing, float* scratch, float* out_frames, float* out_sum,
                    void* stream);
+/* The same with the frames in their storage type (MC_STORE_F32 / MC_STORE_F16; outputs stay fp32).
+ * fp16 frames are resampled straight from the fp16 bytes (half the HBM read) when w % 8 == 0, the
+ * frames are 16-byte aligned and the lattice is sparse (32 pixel rows span <= 1.5 lattice cells);
+ * otherwise MC_ERR_UNSUPPORTED: widen the stack and call mc_warp_frames. */
+int mc_warp_frames_t(const void* frames, int storage, int nframes, int h, int w, const float* lattice,
+                     int GH, int GW, float pixel_spacing, float* scratch, float* out_frames, float* out_sum,
+                     void* stream);
 
 /* Rigid special case of mc_warp_frames: a (2,nt,1,1) field gives each frame ONE shift,
  * shifts_px[f] = (sy, sx) in pixels (device).  The coordinate chain is then separable

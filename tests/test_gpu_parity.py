@@ -1440,3 +1440,50 @@ def test_c5_full_frame_size_properties(mc, dev):
     inside = frames != 0  # zero-outside pixels stay zero instead of picking up the offset
     lin = (twice - (2.0 * frames + 1.0)).abs()
     assert float(lin[inside].max()) <= 1e-5 * float(frames.abs().max())
+
+
+# ------------------------------------------------------------------ fp16 frames read natively (N2 / C5)
+
+
+def test_fp16_statistics_and_patch_rows_read_natively(mc, dev):
+    """mc_central_box_stats_t and the 1024-px patch row kernel on fp16 bytes == the same on the fp32
+    up-cast of those bytes (bit for bit: the widening is exact and happens in the load)."""
+    from torch_motion_correction_amd import engine
+
+    st, _, _ = drift_stack(3, 1100, 1600, seed=5)
+    h16 = st.half().to(dev)
+    up = h16.float()
+    assert torch.equal(engine.central_box_stats(h16), engine.central_box_stats(up))
+    a, pa = mc.estimate_motion_cross_correlation_patches(h16, 1.0, patch_sidelength=1024)
+    b, pb = mc.estimate_motion_cross_correlation_patches(up, 1.0, patch_sidelength=1024)
+    assert torch.equal(pa, pb) and torch.equal(a, b)
+    # a patch size the native kernel does not cover: widened internally, same answer
+    a, _ = mc.estimate_motion_cross_correlation_patches(h16, 1.0, patch_sidelength=256)
+    b, _ = mc.estimate_motion_cross_correlation_patches(up, 1.0, patch_sidelength=256)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shape,grid,ps", [((4, 300, 520), (3, 4), 1.0), ((3, 200, 264), (2, 2), 0.83),
+                                           ((3, 130, 96), (2, 3), 1.0), ((2, 100, 101), (2, 2), 1.0)])
+def test_fp16_frames_through_the_field_warp(mc, dev, shape, grid, ps):
+    """The deformation-field warp on fp16 frames (window DMA'd as fp16, widened in LDS; borders,
+    edge tiles, non-unit spacing; a row length that is not a multiple of 8 falls back to a widened
+    copy) == the warp of the fp32 up-cast, frames and sum, bit for bit."""
+    t, h, w = shape
+    g = torch.Generator().manual_seed(h + w)
+    st16 = (torch.randn(t, h, w, generator=g) * 2 + 1).half().to(dev)
+    field = (torch.randn(2, t, *grid, generator=g) * 1.5).to(dev)
+    for gt in ("bspline", "catmull_rom"):
+        sa, fa = mc.motion_correct_sum(st16, field, ps, grid_type=gt, return_frames=True)
+        sb, fb = mc.motion_correct_sum(st16.float(), field, ps, grid_type=gt, return_frames=True)
+        assert fa.dtype == torch.float32 and torch.equal(fa, fb) and torch.equal(sa, sb)
+    # rough field: some tile-frames fail the regularity test and take the generic kernel
+    rough = (torch.randn(2, t, 6, 6, generator=g) * 6).to(dev)
+    fa = mc.correct_motion(st16, rough, ps, grid_type="bspline")
+    fb = mc.correct_motion(st16.float(), rough, ps, grid_type="bspline")
+    assert torch.equal(fa, fb)
+    # and against the oracle on the up-cast (SURVEY Q11)
+    ref = oracle.correct_motion(st16.float().cpu(), field.cpu(), ps, grid_type="bspline")
+    got = mc.correct_motion(st16, field, ps, grid_type="bspline")
+    knife = knife_edge_mask(st16.float().cpu(), field.cpu(), ps, "bspline")
+    assert_frames_close(got, ref, knife, max_excluded=0.05)

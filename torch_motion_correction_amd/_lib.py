@@ -43,12 +43,14 @@ SIGNATURES = {
     "mc_circle_mask": [vp, vp, i32, i32, f32, f32, vp],
     "mc_xc_filter": [vp, GP, f32, f32, f32, f32, vp],
     "mc_central_box_stats": [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp],
+    "mc_central_box_stats_t": [vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp],
     "mc_normalize": [vp, vp, i64, vp, vp],
     "mc_xc_rows_lds_bytes": [GP],
     "mc_xc_row_engine": [i32],
     "mc_xc_col_engine": [i32],
     "mc_xc_rows_forward": [vp, vp, i64, vp, vp, vp, vp, vp, i32, GP, vp],
     "mc_xc_rows_forward_dual": [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, GP, vp, vp],
+    "mc_xc_rows_forward_dual_t": [vp, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, GP, vp, vp],
     "mc_xc_rows_forward_stats": [vp, vp, i64, vp, vp, vp, vp, i32, GP, i32, i32, i32, i32, vp, vp, vp, vp, vp],
     "mc_xc_cols_forward": [vp, vp, vp, vp, i32, GP, vp],
     "mc_xc_cols_forward_fix": [vp, vp, vp, vp, i32, GP, vp, vp, vp],
@@ -64,6 +66,7 @@ SIGNATURES = {
     "mc_spline_lattice": [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, i32, vp, vp],
     "mc_warp_scratch_bytes": [i32, i32, i32, i32, i32, C.POINTER(C.c_int64)],
     "mc_warp_frames": [vp, i32, i32, i32, vp, i32, i32, f32, vp, vp, vp, vp],
+    "mc_warp_frames_t": [vp, i32, i32, i32, i32, vp, i32, i32, f32, vp, vp, vp, vp],
     "mc_warp_rigid_scratch_bytes": [i32, i32, i32, C.POINTER(C.c_int64)],
     "mc_warp_rigid": [vp, i32, i32, i32, vp, vp, vp, vp, vp],
     "mc_warp_rigid_phase": [vp, i32, i32, i32, vp, vp, vp, vp, i32, vp],

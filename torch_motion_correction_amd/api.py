@@ -43,7 +43,12 @@ def _out_device(image: torch.Tensor, device):
     return image.device if device is None else torch.device(device)
 
 
-def _stage(x: torch.Tensor, dev) -> torch.Tensor:
+def _stage(x: torch.Tensor, dev, keep_half: bool = False) -> torch.Tensor:
+    """The tensor on the GPU as contiguous fp32 -- or, `keep_half`, an fp16 stack as it is: the patch
+    estimator and the deformation-field warp read fp16 frames straight from their bytes (BASELINE
+    C5; no fp32 copy of the movie, half the HBM read)."""
+    if keep_half and x.dtype == torch.float16:
+        return x.detach().to(device=dev).contiguous()
     return x.detach().to(device=dev, dtype=torch.float32).contiguous()
 
 
@@ -159,7 +164,9 @@ def estimate_motion_cross_correlation_patches(
     (t,gh,gw,3) int64 patch centres)."""
     out_dev = _out_device(image, device)
     dev = require_gpu(out_dev)
-    img = _stage(image, dev)
+    # an fp16 stack stays fp16 unless a prior field has to be applied first (that path normalises
+    # and resamples in fp32)
+    img = _stage(image, dev, keep_half=deformation_field is None)
     t, h, w = img.shape
     ref = t // 2 if reference_frame is None else reference_frame
     if reference_strategy not in ("middle_frame", "mean_except_current"):
@@ -219,7 +226,7 @@ def correct_motion(image, deformation_grid, pixel_spacing, grad=False, grid_type
         raise NotImplementedError("grad=True is not supported by the HIP path (forward only)")
     out_dev = _out_device(image, device)
     dev = require_gpu(out_dev)
-    img = _stage(image, dev)
+    img = _stage(image, dev, keep_half=True)
     lat = engine.frame_lattices(_stage(deformation_grid, dev), img.shape[0], grid_type)
     frames, _ = engine.warp(img, lat, float(pixel_spacing), want_frames=True, want_sum=False,
                             rigid=RIGID_FAST_PATH and _is_rigid(deformation_grid))
@@ -324,7 +331,7 @@ def motion_correct_sum(image, deformation_grid, pixel_spacing, grid_type="catmul
     ``dose_weight`` step (examples/ttMotion.py:331-351; see ``dose_weighted_sum``)."""
     out_dev = _out_device(image, device)
     dev = require_gpu(out_dev)
-    img = _stage(image, dev)
+    img = _stage(image, dev, keep_half=True)
     lat = engine.frame_lattices(_stage(deformation_grid, dev), img.shape[0], grid_type)
     rigid = RIGID_FAST_PATH and _is_rigid(deformation_grid)
     if dose_per_frame is None:

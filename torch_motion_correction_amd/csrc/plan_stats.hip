@@ -290,7 +290,8 @@ __global__ __launch_bounds__(256) void cond_vec_kernel(const void* __restrict__ 
 }
 
 // ------------------------------------------------------------------ statistics
-__global__ __launch_bounds__(256) void box_stats_partial(const float* __restrict__ stack, int h,
+template <typename T>
+__global__ __launch_bounds__(256) void box_stats_partial(const T* __restrict__ stack, int h,
                                                          int w, int hl, int hu, int wl, int wu,
                                                          double* __restrict__ acc) {
   // grid: (row chunks, t); each block reduces rows [r0, r1) of one frame's box
@@ -299,18 +300,25 @@ __global__ __launch_bounds__(256) void box_stats_partial(const float* __restrict
   const int r0 = hl + blockIdx.x * rows_per;
   int r1 = r0 + rows_per;
   if (r1 > hu) r1 = hu;
-  const float* frame = stack + (int64_t)f * h * w;
+  const T* frame = stack + (int64_t)f * h * w;
   double s = 0.0, q = 0.0;
-  // 16-byte loads when every row segment of the box is 16-byte aligned and a multiple of 4 long
+  // 4 samples per load when every row segment of the box is aligned to it and a multiple of 4 long
   const bool vec = ((w | wl | (wu - wl)) & 3) == 0 && (reinterpret_cast<uintptr_t>(stack) & 15) == 0 &&
                    ((((int64_t)h * w) & 3) == 0);
   for (int y = r0; y < r1; ++y) {
-    const float* row = frame + (int64_t)y * w;
+    const T* row = frame + (int64_t)y * w;
     float ps = 0.f, pq = 0.f;
     int n = 0;
     if (vec) {
       for (int x = wl + 4 * threadIdx.x; x < wu; x += 1024) {
-        const float4 v = *reinterpret_cast<const float4*>(row + x);
+        float4 v;
+        if (sizeof(T) == 4) {
+          v = *reinterpret_cast<const float4*>(row + x);
+        } else {
+          typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+          const h4 hv = *reinterpret_cast<const h4*>(row + x);
+          v = make_float4((float)hv.x, (float)hv.y, (float)hv.z, (float)hv.w);
+        }
         ps += (v.x + v.y) + (v.z + v.w);
         pq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         if (++n == 4) {  // flush the fp32 partials every 16 samples, as the scalar loop does
@@ -322,7 +330,7 @@ __global__ __launch_bounds__(256) void box_stats_partial(const float* __restrict
       continue;
     }
     for (int x = wl + threadIdx.x; x < wu; x += 256) {
-      const float v = row[x];
+      const float v = (float)row[x];
       ps += v;
       pq += v * v;
       if (++n == 16) {  // flush the fp32 partials regularly
@@ -487,15 +495,25 @@ int mc_condition_movie(const void* raw, int kind, const float* gain, int nframes
 
 int mc_central_box_stats(const float* stack, int t, int h, int w, int hl, int hu, int wl, int wu,
                          double* acc, float* out3, void* stream) {
+  return mc_central_box_stats_t(stack, MC_STORE_F32, t, h, w, hl, hu, wl, wu, acc, out3, stream);
+}
+
+int mc_central_box_stats_t(const void* stack, int storage, int t, int h, int w, int hl, int hu, int wl,
+                           int wu, double* acc, float* out3, void* stream) {
   if (!stack || !acc || !out3 || t < 1 || hl < 0 || hu > h || wl < 0 || wu > w || hl >= hu ||
       wl >= wu)
     return MC_ERR_ARG;
+  if (storage != MC_STORE_F32 && storage != MC_STORE_F16) return MC_ERR_UNSUPPORTED;
   hipError_t e = hipMemsetAsync(acc, 0, 2 * sizeof(double), (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
   int chunks = (hu - hl + 15) / 16;
   if (chunks > 256) chunks = 256;
-  hipLaunchKernelGGL(box_stats_partial, dim3(chunks, t), dim3(256), 0, (hipStream_t)stream, stack,
-                     h, w, hl, hu, wl, wu, acc);
+  if (storage == MC_STORE_F32)
+    hipLaunchKernelGGL(box_stats_partial<float>, dim3(chunks, t), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)stack, h, w, hl, hu, wl, wu, acc);
+  else
+    hipLaunchKernelGGL(box_stats_partial<_Float16>, dim3(chunks, t), dim3(256), 0, (hipStream_t)stream,
+                       (const _Float16*)stack, h, w, hl, hu, wl, wu, acc);
   const double count = (double)t * (hu - hl) * (wu - wl);
   hipLaunchKernelGGL(box_stats_final, dim3(1), dim3(1), 0, (hipStream_t)stream, acc, count, out3);
   return mc_check_launch();

@@ -1414,9 +1414,11 @@ __global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES, GW2_MINW) void warp_field
 #define GW3_RW (RIGID_WAVES * RIGID_ROWS / GW3_WAVES)  // pixel rows per wave (2)
 #define GW3_EROWS 6                                     // lattice rows staged per tile
 #define GW3_PLAN_MAX 128                                // frames whose plan entries are kept in LDS
+#define GW3_QH 36                                       // 16-byte units (8 fp16 samples) per stage row
+#define GW3_STAGE_UNITS ((((GW_ROWS * GW3_QH) + 63) / 64) * 64)
 
 // plan[f * nt + tile] = {wy0, ax, mgy | mgx << 8 | irregular << 16, first staged lattice row R0}
-__global__ __launch_bounds__(64) void warp_field_plan(FieldArgs fa, int unit_ps, int4* __restrict__ plan) {
+__global__ __launch_bounds__(64) void warp_field_plan(FieldArgs fa, int unit_ps, int half, int4* __restrict__ plan) {
   const WarpArgs& a = fa.w;
   const int nt = a.tiles_x * a.tiles_y;
   const int tl = blockIdx.x, f = blockIdx.y;
@@ -1486,7 +1488,10 @@ __global__ __launch_bounds__(64) void warp_field_plan(FieldArgs fa, int unit_ps,
     const float lim = 4.f * (fh + fw);
     const float dy = fminf(fmaxf(floorf(grid_chain((float)yc + sy, fh)) - (float)yc, -lim), lim);
     const float dx = fminf(fmaxf(floorf(grid_chain((float)xc + sx, fw)) - (float)xc, -lim), lim);
-    out = make_int4(yt + (int)dy - 1 - mgy, (xt + (int)dx - 1 - mgx) & ~3, mgy | (mgx << 8), R0);
+    // fp32 frames: the window starts at a 16-byte aligned column; fp16 frames: at the exact column
+    // (the fp16 -> fp32 staging pass places it, warp_field3)
+    const int axx = xt + (int)dx - 1 - mgx;
+    out = make_int4(yt + (int)dy - 1 - mgy, half ? axx : (axx & ~3), mgy | (mgx << 8), R0);
   }
   if (lane == 0) {
     plan[(int64_t)f * nt + tl] = out;
@@ -1494,14 +1499,21 @@ __global__ __launch_bounds__(64) void warp_field_plan(FieldArgs fa, int unit_ps,
   }
 }
 
-template <bool WRITE_FRAMES, bool WRITE_SUM, bool UNIT_PS>
+template <bool WRITE_FRAMES, bool WRITE_SUM, bool UNIT_PS, bool HALF>
 __global__ __launch_bounds__(RIGID_LANES* GW3_WAVES, 4) void warp_field3(FieldArgs fa, const int4* __restrict__ plan) {
   const WarpArgs& a = fa.w;
   extern __shared__ __attribute__((aligned(16))) char smem_gw[];
-  // [window 0][window 1][E 0][E 1]
-  auto win_of = [&](int bi) { return reinterpret_cast<float4*>(smem_gw) + bi * GW_QUADS_PAD; };
+  // fp32 frames: [window 0][window 1][E 0][E 1].  fp16 frames: [fp32 window][fp16 stage 0][fp16
+  // stage 1][E 0][E 1] -- the DMA lands the raw fp16 window in a stage, one pass per frame widens it
+  // into the single fp32 window (10 elements per thread; doing it per tap would be 24 instructions
+  // per pixel), so the HBM side moves half the bytes and the arithmetic is unchanged.
+  auto win_of = [&](int bi) { return reinterpret_cast<float4*>(smem_gw) + (HALF ? 0 : bi) * GW_QUADS_PAD; };
+  auto stage_of = [&](int bi) {
+    return reinterpret_cast<float4*>(smem_gw + GW_QUADS_PAD * 16) + bi * GW3_STAGE_UNITS;
+  };
   auto est_of = [&](int bi) {
-    return reinterpret_cast<float*>(smem_gw + 2 * GW_QUADS_PAD * 16) + bi * (2 * GW3_EROWS * 256);
+    return reinterpret_cast<float*>(smem_gw + (HALF ? GW_QUADS_PAD * 16 + 2 * GW3_STAGE_UNITS * 16
+                                                    : 2 * GW_QUADS_PAD * 16)) + bi * (2 * GW3_EROWS * 256);
   };
   __shared__ int s_ytap[RIGID_WAVES * RIGID_ROWS][4];
   __shared__ float s_ycoef[RIGID_WAVES * RIGID_ROWS][4];
@@ -1553,6 +1565,22 @@ __global__ __launch_bounds__(RIGID_LANES* GW3_WAVES, 4) void warp_field3(FieldAr
     const int nrows = RIGID_WAVES * RIGID_ROWS + 3 + 2 * mgy;
     int nq = (RIGID_LANES * 4 + 6 + 2 * mgx + 3) / 4;
     nq = nq < GW_QUADS ? nq : GW_QUADS;
+    if (HALF) {  // 16-byte units of 8 samples from the 8-aligned column at or left of the window
+      const _Float16* frh = reinterpret_cast<const _Float16*>(a.frames) + (int64_t)f * hw;
+      const int axa = p.y & ~7;
+      const int nqh = (p.y - axa + RIGID_LANES * 4 + 3 + 2 * mgx + 7) / 8;  // <= GW3_QH
+      for (int i = wave; i < GW3_STAGE_UNITS / 64; i += GW3_WAVES) {
+        const int q = i * 64 + lane;
+        const int tr = q / GW3_QH, qc = q - tr * GW3_QH;
+        if (tr < nrows && qc < nqh) {
+          int r = p.x + tr;
+          r = r < 0 ? 0 : (r > h - 1 ? h - 1 : r);
+          int c = axa + 8 * qc;
+          c = c < 0 ? 0 : (c > w - 8 ? w - 8 : c);  // clamped units are never read (see widen)
+          __builtin_amdgcn_global_load_lds(frh + (int64_t)r * w + c, (lds_vptr)(stage_of(bi) + i * 64), 16, 0, 0);
+        }
+      }
+    } else
     for (int i = wave; i < GW_QUADS_PAD / 64; i += GW3_WAVES) {
       const int q = i * 64 + lane;
       const int tr = q / GW_QUADS, qc = q - tr * GW_QUADS;
@@ -1575,10 +1603,32 @@ __global__ __launch_bounds__(RIGID_LANES* GW3_WAVES, 4) void warp_field3(FieldAr
     }
   };
 
+  // fp16: stage `bi` -> the fp32 window.  Window column j is absolute column p.y + j; border padding
+  // = the clipped column, which always lies in an unclamped unit of the stage (w % 8 == 0).
+  auto widen = [&](const int4 p, int bi) {
+    if (p.z >> 16) return;
+    const int mgy = p.z & 255, mgx = (p.z >> 8) & 255;
+    const int nrows = RIGID_WAVES * RIGID_ROWS + 3 + 2 * mgy;
+    const int ncols = RIGID_LANES * 4 + 3 + 2 * mgx;  // <= GW_STRIDE
+    const int axa = p.y & ~7;
+    const _Float16* st = reinterpret_cast<const _Float16*>(stage_of(bi));
+    float* wn = reinterpret_cast<float*>(win_of(0));
+    for (int i = tid; i < nrows * ncols; i += RIGID_LANES * GW3_WAVES) {
+      const int tr = i / ncols, j = i - tr * ncols;
+      int xa = p.y + j;
+      xa = xa < 0 ? 0 : (xa > w - 1 ? w - 1 : xa);
+      wn[tr * GW_STRIDE + j] = (float)st[tr * (8 * GW3_QH) + (xa - axa)];
+    }
+  };
+
   int4 pc = fetch_plan(0);
   dma(0, pc, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (HALF) {
+    widen(pc, 0);
+    __syncthreads();
+  }
   for (int f = 0; f < a.nframes; ++f) {
     const int bi = f & 1;
     int4 pn = pc;
@@ -1593,7 +1643,7 @@ __global__ __launch_bounds__(RIGID_LANES* GW3_WAVES, 4) void warp_field3(FieldAr
       nq = nq < GW_QUADS ? nq : GW_QUADS;
       float* const tile = reinterpret_cast<float*>(win_of(bi));
       const float* const es = est_of(bi);
-      if (ax < 0 || ax + 4 * nq > w) {  // border padding: clipped columns (edge tiles only)
+      if (!HALF && (ax < 0 || ax + 4 * nq > w)) {  // border padding: clipped columns (edge tiles only)
         for (int i = tid; i < nrows * GW_STRIDE; i += RIGID_LANES * GW3_WAVES) {
           const int tr = i / GW_STRIDE, e = i - tr * GW_STRIDE;
           const int c = ax + e;
@@ -1606,7 +1656,8 @@ __global__ __launch_bounds__(RIGID_LANES* GW3_WAVES, 4) void warp_field3(FieldAr
         }
         __syncthreads();
       }
-      const bool interior = whole_tile && wy0 >= 0 && wy0 + nrows <= h && ax >= 0 && ax + 4 * nq <= w;
+      const bool interior = whole_tile && wy0 >= 0 && wy0 + nrows <= h && ax >= 0 &&
+                            ax + (HALF ? RIGID_LANES * 4 + 3 + 2 * mgx : 4 * nq) <= w;
       const int oy = 1 + wy0, ox = 1 + ax;
       // One pixel at a time.  (Measured alternatives, same results, none faster: the wave's two rows
       // statement by statement for two independent chains per lane, 3.2 ms instead of 2.96; the same
@@ -1666,6 +1717,10 @@ __global__ __launch_bounds__(RIGID_LANES* GW3_WAVES, 4) void warp_field3(FieldAr
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA of f+1 (and this frame's stores)
     __syncthreads();  // buffer bi is free again, buffer bi^1 is complete
+    if (HALF && f + 1 < a.nframes) {
+      widen(pn, bi ^ 1);
+      __syncthreads();
+    }
     pc = pn;
   }
   if (WRITE_SUM) {
@@ -1685,7 +1740,7 @@ __global__ __launch_bounds__(RIGID_LANES* GW3_WAVES, 4) void warp_field3(FieldAr
 // Tile-frames warp_field flagged as irregular: generic per-pixel gathers from global
 // memory (border padding by clipping every tap coordinate).  One workgroup per tile, so
 // the += on out_sum cannot race.
-template <bool UNIT_PS>
+template <bool UNIT_PS, bool HALF = false>
 __global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES) void warp_field_slow(FieldArgs fa, int write_frames,
                                                                            int write_sum) {
   const WarpArgs& a = fa.w;
@@ -1710,6 +1765,7 @@ __global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES) void warp_field_slow(Fiel
     for (int f = 0; f < a.nframes; ++f) {
       if (!fa.flags[(int64_t)f * nt + tl]) continue;
       const float* fr = a.frames + (int64_t)f * hw;
+      const _Float16* frh = reinterpret_cast<const _Float16*>(a.frames) + (int64_t)f * hw;
       const float* E = a.etab + (int64_t)f * 2 * a.GH * w + x;
       float sy = dot4(yc4, E[(int64_t)yt4.x * w], E[(int64_t)yt4.y * w], E[(int64_t)yt4.z * w],
                       E[(int64_t)yt4.w * w]);
@@ -1729,9 +1785,12 @@ __global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES) void warp_field_slow(Fiel
       float rowv[4];
       for (int ii = 0; ii < 4; ++ii) {
         const float ty = fminf(fmaxf(fy + (float)(ii - 1), 0.f), fh - 1.f);
-        const float* rp = fr + (int64_t)(int)ty * w;
+        const int64_t ro = (int64_t)(int)ty * w;
         float t4[4];
-        for (int j = 0; j < 4; ++j) t4[j] = rp[(int)fminf(fmaxf(fx + (float)(j - 1), 0.f), fw - 1.f)];
+        for (int j = 0; j < 4; ++j) {
+          const int64_t o = ro + (int)fminf(fmaxf(fx + (float)(j - 1), 0.f), fw - 1.f);
+          t4[j] = HALF ? (float)frh[o] : fr[o];
+        }
         rowv[ii] = gw_dot4(wx, t4[0], t4[1], t4[2], t4[3]);
       }
       float o = gw_dot4(wy, rowv[0], rowv[1], rowv[2], rowv[3]);
@@ -1862,6 +1921,20 @@ int mc_warp_scratch_bytes(int nframes, int h, int w, int GH, int GW, int64_t* by
 int mc_warp_frames(const float* frames, int nframes, int h, int w, const float* lattice, int GH,
                    int GW, float pixel_spacing, float* scratch, float* out_frames, float* out_sum,
                    void* stream) {
+  return mc_warp_frames_t(frames, MC_STORE_F32, nframes, h, w, lattice, GH, GW, pixel_spacing, scratch,
+                          out_frames, out_sum, stream);
+}
+
+int mc_warp_frames_t(const void* frames_any, int storage, int nframes, int h, int w, const float* lattice,
+                     int GH, int GW, float pixel_spacing, float* scratch, float* out_frames, float* out_sum,
+                     void* stream) {
+  if (storage != MC_STORE_F32 && storage != MC_STORE_F16) return MC_ERR_UNSUPPORTED;
+  const bool half = storage == MC_STORE_F16;
+  // fp16 frames take the LDS-staged kernel only: 16-byte rows of 8 samples and the reference's sparse
+  // lattice (10 nodes per patch); anything else is MC_ERR_UNSUPPORTED and the caller widens the stack
+  if (half && ((w % 8) || (((uintptr_t)frames_any) & 15) || (int64_t)32 * (GH - 1) * 2 > (int64_t)3 * (h - 1)))
+    return MC_ERR_UNSUPPORTED;
+  const float* frames = static_cast<const float*>(frames_any);
   if (!frames || !lattice || !scratch || (!out_frames && !out_sum)) return MC_ERR_ARG;
   if (nframes < 1 || h < 2 || w < 2 || GH < 1 || GW < 1 || !(pixel_spacing > 0.f)) return MC_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -1905,31 +1978,40 @@ int mc_warp_frames(const float* frames, int nframes, int h, int w, const float* 
     }
     // version 3 stages <= GW3_EROWS lattice rows per tile: 32 pixel rows must span <= 1.5 lattice
     // cells (always for the reference's 10 nodes per patch; not for a per-pixel lattice)
-    if (field_version == 3 && (int64_t)32 * (GH - 1) * 2 <= (int64_t)3 * (h - 1)) {
+    if ((field_version == 3 || half) && (int64_t)32 * (GH - 1) * 2 <= (int64_t)3 * (h - 1)) {
       int4* plan = reinterpret_cast<int4*>(fa.flags + field_flag_bytes(nframes, h, w));
-      hipLaunchKernelGGL(warp_field_plan, dim3(a.tiles_x * a.tiles_y, nframes), dim3(64), 0, s, fa, unit ? 1 : 0, plan);
-      const size_t lds3 = (size_t)2 * GW_QUADS_PAD * 16 + (size_t)2 * 2 * GW3_EROWS * 256 * 4;
+      hipLaunchKernelGGL(warp_field_plan, dim3(a.tiles_x * a.tiles_y, nframes), dim3(64), 0, s, fa, unit ? 1 : 0,
+                         half ? 1 : 0, plan);
+      const size_t lds3 = (half ? (size_t)GW_QUADS_PAD * 16 + (size_t)2 * GW3_STAGE_UNITS * 16
+                                : (size_t)2 * GW_QUADS_PAD * 16) + (size_t)2 * 2 * GW3_EROWS * 256 * 4;
       dim3 block3(RIGID_LANES, GW3_WAVES);
-#define MC_GW3_GO(F, S, U)                                                                        \
+#define MC_GW3_GO(F, S, U, H)                                                                     \
   do {                                                                                            \
-    auto k = warp_field3<F, S, U>;                                                                \
+    auto k = warp_field3<F, S, U, H>;                                                             \
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3); \
     hipLaunchKernelGGL(k, grid, block3, lds3, s, fa, (const int4*)plan);                          \
   } while (0)
-#define MC_GW3_LAUNCH(F, S)          \
-  do {                               \
-    if (unit) MC_GW3_GO(F, S, true); \
-    else MC_GW3_GO(F, S, false);     \
+#define MC_GW3_LAUNCH(F, S)                             \
+  do {                                                  \
+    if (unit && half) MC_GW3_GO(F, S, true, true);      \
+    else if (unit) MC_GW3_GO(F, S, true, false);        \
+    else if (half) MC_GW3_GO(F, S, false, true);        \
+    else MC_GW3_GO(F, S, false, false);                 \
   } while (0)
       if (out_frames && out_sum) MC_GW3_LAUNCH(true, true);
       else if (out_frames) MC_GW3_LAUNCH(true, false);
       else MC_GW3_LAUNCH(false, true);
 #undef MC_GW3_LAUNCH
 #undef MC_GW3_GO
-      if (unit) hipLaunchKernelGGL((warp_field_slow<true>), grid, block, 0, s, fa, out_frames ? 1 : 0, out_sum ? 1 : 0);
-      else hipLaunchKernelGGL((warp_field_slow<false>), grid, block, 0, s, fa, out_frames ? 1 : 0, out_sum ? 1 : 0);
+#define MC_SLOW_GO(U, H) hipLaunchKernelGGL((warp_field_slow<U, H>), grid, block, 0, s, fa, out_frames ? 1 : 0, out_sum ? 1 : 0)
+      if (unit && half) MC_SLOW_GO(true, true);
+      else if (unit) MC_SLOW_GO(true, false);
+      else if (half) MC_SLOW_GO(false, true);
+      else MC_SLOW_GO(false, false);
+#undef MC_SLOW_GO
       return mc_check_launch();
     }
+    if (half) return MC_ERR_UNSUPPORTED;
 #define MC_GW_LAUNCH(F, S)                                                                  \
   do {                                                                                      \
     if (field_version == 1) {  /* (version 3 falls back to 2 for dense lattices) */          \

@@ -511,6 +511,15 @@ __device__ __forceinline__ wf2 wf5_ld2(const float* p) {  // 4-byte aligned 8-by
   __builtin_memcpy(&v, p, 8);
   return v;
 }
+// two adjacent samples of fp16 storage (a 2-byte aligned 4-byte load), widened to fp32: the
+// reference has no fp16 path at all (rfftn rejects Half on the CPU); the result is what
+// it computes on the fp32 up-cast of the same stack
+typedef _Float16 wf_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ wf2 wf5_ld2h(const _Float16* p) {
+  wf_h2 v;
+  __builtin_memcpy(&v, p, 4);
+  return wf2{(float)v.x, (float)v.y};
+}
 
 __device__ __forceinline__ void wf5_fft(wf2 (&A)[8], int t, wf2* slab, const wf2* twA, const wf2* twB,
                                         const wf2* twK, wf2 (&X)[2]) {
@@ -548,9 +557,9 @@ __device__ __forceinline__ void wf5_fft(wf2 (&A)[8], int t, wf2* slab, const wf2
   X[1] = wf_unpack(z[1], m1, twK[t + 64]);
 }
 
-template <bool DUAL>
+template <bool DUAL, bool HALF>
 __global__ __launch_bounds__(256) void xc_rows_fwd_wave512(
-    const float* __restrict__ src, const int64_t* __restrict__ job_off, int64_t row_stride,
+    const void* __restrict__ src_any, const int64_t* __restrict__ job_off, int64_t row_stride,
     const int* __restrict__ expo_a, const int* __restrict__ expo_b, const float* __restrict__ mask,
     const float* __restrict__ mean_rstd, cfloat* __restrict__ T1a, cfloat* __restrict__ T1b,
     const cfloat* __restrict__ tw_row, XcGeom g, const int2* __restrict__ chord) {
@@ -585,7 +594,8 @@ __global__ __launch_bounds__(256) void xc_rows_fwd_wave512(
   const float mean = mean_rstd ? mean_rstd[0] : 0.f;
   const float rstd = mean_rstd ? mean_rstd[1] : 1.f;
   const int ea = expo_a[job], eb = DUAL ? expo_b[job] : 1;
-  const float* base = src + job_off[job];
+  const float* base = HALF ? nullptr : static_cast<const float*>(src_any) + job_off[job];
+  const _Float16* base_h = HALF ? static_cast<const _Float16*>(src_any) + job_off[job] : nullptr;
   cfloat* outa = T1a + (int64_t)job * g.nkx * g.ny;
   cfloat* outb = DUAL ? T1b + (int64_t)job * g.nkx * g.ny : nullptr;
   const int r16 = grp * WF5_ROWS_PER_WG;
@@ -602,13 +612,15 @@ __global__ __launch_bounds__(256) void xc_rows_fwd_wave512(
     const int xlo = chord ? chord[y].x : bxlo, xhi = chord ? chord[y].y + 2 : bxhi;
     int tl = t;
     asm volatile("" : "+v"(tl));  // per-row addresses are re-derived, not carried (registers)
-    const float* row = base + (int64_t)y * row_stride;
+    const float* row = HALF ? nullptr : base + (int64_t)y * row_stride;
+    const _Float16* row_h = HALF ? base_h + (int64_t)y * row_stride : nullptr;
     const float* mrow = mask + (int64_t)y * g.W;
     wf2 A[8], Bv[8], mk[8];
 #pragma unroll
     for (int n1 = 0; n1 < 8; ++n1) {  // all sixteen loads in flight before anything is used
       const int x = 128 * n1 + 2 * tl;
-      A[n1] = wf5_ld2(row + min(max(x, xlo), xhi));  // outside the support: mask == 0
+      const int xc = min(max(x, xlo), xhi);  // outside the support: mask == 0
+      A[n1] = HALF ? wf5_ld2h(row_h + xc) : wf5_ld2(row + xc);
       mk[n1] = *reinterpret_cast<const wf2*>(mrow + x);
     }
 #pragma unroll
@@ -1558,6 +1570,16 @@ int mc_xc_rows_forward_dual(const float* src, const int64_t* job_off, int64_t ro
                             const int* expo_a, const int* expo_b, const float* mask,
                             const float* mean_rstd, void* T1a, void* T1b, const void* tw_row,
                             int njobs, const mc_xc_geom* q, const int* row_chord, void* stream) {
+  return mc_xc_rows_forward_dual_t(src, MC_STORE_F32, job_off, row_stride, expo_a, expo_b, mask, mean_rstd,
+                                   T1a, T1b, tw_row, njobs, q, row_chord, stream);
+}
+
+int mc_xc_rows_forward_dual_t(const void* src, int storage, const int64_t* job_off, int64_t row_stride,
+                              const int* expo_a, const int* expo_b, const float* mask,
+                              const float* mean_rstd, void* T1a, void* T1b, const void* tw_row,
+                              int njobs, const mc_xc_geom* q, const int* row_chord, void* stream) {
+  if (storage != MC_STORE_F32 && storage != MC_STORE_F16) return MC_ERR_UNSUPPORTED;
+  const bool half = storage == MC_STORE_F16;
   XcGeom g;
   int rc = geom_from(q, &g, true, false);
   if (rc) return rc;
@@ -1566,14 +1588,18 @@ int mc_xc_rows_forward_dual(const float* src, const int64_t* job_off, int64_t ro
   if (g.W != 2 * WF5_N || g.nkx > 128 || (g.ny % 8) || (reinterpret_cast<uintptr_t>(mask) & 7))
     return MC_ERR_UNSUPPORTED;
   dim3 grid(njobs, (g.ny + WF5_ROWS_PER_WG - 1) / WF5_ROWS_PER_WG);
-  if (expo_b)
-    hipLaunchKernelGGL(xc_rows_fwd_wave512<true>, grid, dim3(256), 0, (hipStream_t)stream, src, job_off,
-                       row_stride, expo_a, expo_b, mask, mean_rstd, (cfloat*)T1a, (cfloat*)T1b,
-                       (const cfloat*)tw_row, g, (const int2*)row_chord);
-  else
-    hipLaunchKernelGGL(xc_rows_fwd_wave512<false>, grid, dim3(256), 0, (hipStream_t)stream, src, job_off,
-                       row_stride, expo_a, (const int*)nullptr, mask, mean_rstd, (cfloat*)T1a,
-                       (cfloat*)nullptr, (const cfloat*)tw_row, g, (const int2*)row_chord);
+#define MC_W512_GO(D, H)                                                                              \
+  hipLaunchKernelGGL((xc_rows_fwd_wave512<D, H>), grid, dim3(256), 0, (hipStream_t)stream, src, job_off, \
+                     row_stride, expo_a, D ? expo_b : (const int*)nullptr, mask, mean_rstd, (cfloat*)T1a, \
+                     D ? (cfloat*)T1b : (cfloat*)nullptr, (const cfloat*)tw_row, g, (const int2*)row_chord)
+  if (expo_b) {
+    if (half) MC_W512_GO(true, true);
+    else MC_W512_GO(true, false);
+  } else {
+    if (half) MC_W512_GO(false, true);
+    else MC_W512_GO(false, false);
+  }
+#undef MC_W512_GO
   return mc_check_launch();
 }
 

@@ -42,15 +42,28 @@ def _i64(a, device):
 # ------------------------------------------------------------------ statistics
 
 
+STORE_F16, STORE_F32 = 2, 3  # MC_STORE_* of include/mcorr.h
+
+
+def storage_of(img: torch.Tensor) -> int:
+    """Frame storage type tag of the *_t entry points: fp32, or fp16 read straight from its bytes."""
+    if img.dtype == torch.float32:
+        return STORE_F32
+    if img.dtype == torch.float16:
+        return STORE_F16
+    raise TypeError(f"frames must be float32 or float16 on the device, got {img.dtype}")
+
+
 def central_box_stats(img: torch.Tensor, frac_low=0.25, frac_high=0.75) -> torch.Tensor:
-    """(mean, 1/std, std) of the central box over all frames (utils.py:49-84)."""
+    """(mean, 1/std, std) of the central box over all frames (utils.py:49-84); fp16 frames are read
+    as they are (statistics of the fp32 up-cast)."""
     lib = _lib.load()
     t, h, w = img.shape
     hl, hu, wl, wu = int(frac_low * h), int(frac_high * h), int(frac_low * w), int(frac_high * w)
     acc = torch.empty(2, dtype=torch.float64, device=img.device)
     out3 = torch.empty(3, dtype=torch.float32, device=img.device)
-    check(lib.mc_central_box_stats(ptr(img), t, h, w, hl, hu, wl, wu, ptr(acc), ptr(out3),
-                                   stream_ptr(img.device)), "mc_central_box_stats")
+    check(lib.mc_central_box_stats_t(ptr(img), storage_of(img), t, h, w, hl, hu, wl, wu, ptr(acc), ptr(out3),
+                                     stream_ptr(img.device)), "mc_central_box_stats")
     return out3
 
 
@@ -98,6 +111,8 @@ def _forward_spectra(src, job_off, row_stride, job_expo, pl, stats, use_mask=Tru
     njobs = int(job_off.numel())
     dual = job_expo_b is not None
     wave = _wave512_ok(g, job_expo, use_mask, min_expo)
+    if src.dtype != torch.float32 and not wave:
+        raise _lib.McorrError("only the wave-per-row patch kernel reads fp16 frames: widen the stack first")
     if dual and not wave:  # no fused kernel for this shape: two ordinary passes
         return (_forward_spectra(src, job_off, row_stride, job_expo, pl, stats, use_mask, use_filter),
                 _forward_spectra(src, job_off, row_stride, job_expo_b, pl, stats, use_mask, use_filter))
@@ -114,9 +129,10 @@ def _forward_spectra(src, job_off, row_stride, job_expo, pl, stats, use_mask=Tru
         expo = None if job_expo is None else job_expo[a : a + n]
         if wave:
             expo_b = job_expo_b[a : a + n] if dual else None
-            check(lib.mc_xc_rows_forward_dual(ptr(src), ptr(off), row_stride, ptr(expo), ptr(expo_b),
-                                              ptr(pl.mask), ptr(stats), ptr(T1), ptr(T1b), ptr(pl.tw_row),
-                                              n, g, ptr(pl.chord) if USE_ROW_CHORDS else None, st),
+            check(lib.mc_xc_rows_forward_dual_t(ptr(src), storage_of(src), ptr(off), row_stride, ptr(expo),
+                                                ptr(expo_b), ptr(pl.mask), ptr(stats), ptr(T1), ptr(T1b),
+                                                ptr(pl.tw_row), n, g,
+                                                ptr(pl.chord) if USE_ROW_CHORDS else None, st),
                   "mc_xc_rows_forward_dual")
         else:
             check(_k1(lib, g, dev, src, off, row_stride, expo, pl.mask if use_mask else None, stats, T1,
@@ -318,6 +334,12 @@ def patch_field(img, stats, pixel_spacing, reference_frame, reference_strategy, 
         raise ValueError(f"patch_sidelength {p} exceeds the frame size {h}x{w}")
     pl = planmod.get_xc_plan(p, p, pixel_spacing, b_factor, frequency_range, dev)
     g = pl.geom
+    if img.dtype != torch.float32 and not (g.W == 1024 and g.nkx <= 128 and g.ny % 8 == 0):
+        # fp16 frames are read natively by the 1024-px patch kernel only (BASELINE C5); any other
+        # patch size goes through the workgroup / chirp-z kernels on a widened copy
+        if stats is not None:
+            pass  # the statistics were taken from the fp16 bytes: identical values
+        img = img.float()
     cy, cx = lattice.patch_grid_centers(t, h, w, p)
     gh, gw = len(cy), len(cx)
     npatch = gh * gw
@@ -431,7 +453,9 @@ def warp(img, lattices, pixel_spacing, want_frames=True, want_sum=False, rigid=F
     t, h, w = img.shape
     dev = img.device
     _, _, GH, GW = lattices.shape
-    frames = torch.empty_like(img) if want_frames else None
+    if rigid and img.dtype != torch.float32:
+        img = img.float()  # the rigid kernel reads fp32 (BASELINE C2); fp16 stacks are widened once
+    frames = torch.empty((t, h, w), dtype=torch.float32, device=dev) if want_frames else None
     total = torch.empty((h, w), dtype=torch.float32, device=dev) if want_sum else None  # the kernels store it
     nbytes = C.c_int64(0)
     if rigid:
@@ -449,9 +473,14 @@ def warp(img, lattices, pixel_spacing, want_frames=True, want_sum=False, rigid=F
         return frames, total
     check(lib.mc_warp_scratch_bytes(t, h, w, GH, GW, C.byref(nbytes)), "mc_warp_scratch_bytes")
     scratch = torch.empty((nbytes.value + 3) // 4, dtype=torch.float32, device=dev)
-    check(lib.mc_warp_frames(ptr(img), t, h, w, ptr(lattices), GH, GW, float(pixel_spacing),
-                             ptr(scratch), ptr(frames), ptr(total), stream_ptr(dev)),
-          "mc_warp_frames")
+    rc = lib.mc_warp_frames_t(ptr(img), storage_of(img), t, h, w, ptr(lattices), GH, GW, float(pixel_spacing),
+                              ptr(scratch), ptr(frames), ptr(total), stream_ptr(dev))
+    if rc == -2 and img.dtype != torch.float32:
+        # fp16 frames outside the LDS-staged kernel's shapes (row length not a multiple of 8, dense
+        # lattice): widen once and take the fp32 kernels
+        rc = lib.mc_warp_frames(ptr(img.float()), t, h, w, ptr(lattices), GH, GW, float(pixel_spacing),
+                                ptr(scratch), ptr(frames), ptr(total), stream_ptr(dev))
+    check(rc, "mc_warp_frames")
     return frames, total
 
 
