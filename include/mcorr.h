@@ -88,6 +88,17 @@ int mc_xc_rows_forward(const float* src, const int64_t* job_off, int64_t row_str
  * (nframes doubles of scratch).  hw = pixels per frame. */
 int mc_condition_movie(const void* raw, int kind, const float* gain, int nframes, int64_t hw,
                        int mean_zero, double* sums, float* out, void* stream);
+/* The same with the example pipeline's hot-pixel step between the gain multiply and the mean-zero
+ * step (examples/ttMotion.py:127-172): a pixel of v = raw * gain is hot when it lies more than
+ * `threshold` population standard deviations from its frame's mean -- the example's detection,
+ * reproduced exactly.  Replacement: the example draws a RANDOM neighbour; here (documented as
+ * ours) the mean of the up-to-8 neighbours that are not hot themselves, from the frame before any
+ * replacement (the frame mean if all are hot).  The mean subtracted afterwards is the mean AFTER
+ * replacement.  stats: 3 * nframes doubles of scratch (sum, sum of squares, replacement delta);
+ * hot_count: nframes ints (number of hot pixels per frame) or NULL. */
+int mc_condition_movie_hot(const void* raw, int kind, const float* gain, int nframes, int h, int w,
+                           int mean_zero, float threshold, double* stats, int* hot_count, float* out,
+                           void* stream);
 
 /* Dose-weighted accumulation in Fourier space (the caller-side exposure filter of the
  * reference's pipeline, examples/ttMotion.py:331-351, crit_exposure_bfactor = -1):
@@ -246,6 +257,13 @@ int mc_field_smooth_center(const float* field_in, float* field_out, int t, int n
 int mc_spline_lattice(const float* data, int c, int nt, int nh, int nw, const int* idx_t,
                       const float* w_t, int NT, const int* idx_y, const float* w_y, int NY,
                       const int* idx_x, const float* w_x, int NX, float* out, void* stream);
+
+/* The same grid at npoints scattered (t, y, x) points -- evaluate_deformation_field on arbitrary
+ * points (deformation_field_utils.py:9-39): per point 4 taps per axis, idx_*[4*i+k] / w_*[4*i+k];
+ * out[npoints][c]. */
+int mc_spline_points(const float* data, int c, int nt, int nh, int nw, const int* idx_t, const float* w_t,
+                     const int* idx_y, const float* w_y, const int* idx_x, const float* w_x, int64_t npoints,
+                     float* out, void* stream);
 
 /* ---- a15/a17/a18: deformation-field warp ------------------------------------------ */
 /* lattice: (nframes, 2, GH, GW) Angstrom shifts on the 10x-oversampled lattice

@@ -23,8 +23,11 @@ for it in range(2):
     torch.cuda.synchronize(); t1 = time.perf_counter()
     total = mc.motion_correct_sum(stack, field, 1.0, grid_type="bspline")
     torch.cuda.synchronize(); t2 = time.perf_counter()
-    print(f"iter {it}: estimate {1e3*(t1-t0):.1f} ms, correct+sum {1e3*(t2-t1):.1f} ms, field {tuple(field.shape)}, "
-          f"peak mem {torch.cuda.max_memory_allocated() / 1e9:.1f} GB", flush=True)
+    dsum = mc.motion_correct_sum(stack, field, 1.0, grid_type="bspline", dose_per_frame=1.0)
+    torch.cuda.synchronize(); t3 = time.perf_counter()
+    print(f"iter {it}: estimate {1e3*(t1-t0):.1f} ms, correct+sum {1e3*(t2-t1):.1f} ms, correct+dose-weighted sum "
+          f"{1e3*(t3-t2):.1f} ms, field {tuple(field.shape)}, peak mem {torch.cuda.max_memory_allocated() / 1e9:.1f} GB", flush=True)
+    del dsum
 fy = field[0].mean(dim=(1, 2)).cpu()
 exp_y = torch.tensor([float(d) for d in dy]); exp_y -= exp_y.mean()
 print("patch-mean field y (first 6):", [round(float(v), 2) for v in fy[:6]], "expected about", [round(float(v), 2) for v in exp_y[:6]])

@@ -1487,3 +1487,72 @@ def test_fp16_frames_through_the_field_warp(mc, dev, shape, grid, ps):
     got = mc.correct_motion(st16, field, ps, grid_type="bspline")
     knife = knife_edge_mask(st16.float().cpu(), field.cpu(), ps, "bspline")
     assert_frames_close(got, ref, knife, max_excluded=0.05)
+
+
+# ------------------------------------------------------------------ N2: hot pixels, scattered spline points
+
+
+def _hot_pixel_reference(x, thr):
+    """numpy restatement of the example's remove_hot_pixels DETECTION (examples/ttMotion.py:145-153)
+    and of this package's deterministic replacement rule; x (t,h,w) float64 = raw * gain."""
+    out = x.copy()
+    counts = []
+    t, h, w = x.shape
+    for f in range(t):
+        fr = x[f]
+        m, sd = fr.mean(), fr.std()
+        hot = (fr > m + thr * sd) | (fr < m - thr * sd)
+        counts.append(int(hot.sum()))
+        for y, xx in zip(*np.where(hot)):
+            vals = [fr[yy, xc] for yy in range(max(0, y - 1), min(h - 1, y + 1) + 1)
+                    for xc in range(max(0, xx - 1), min(w - 1, xx + 1) + 1)
+                    if (yy != y or xc != xx) and not hot[yy, xc]]
+            out[f, y, xx] = np.mean(vals) if vals else m
+    return out, counts
+
+
+@pytest.mark.parametrize("dtype", [torch.uint8, torch.int16, torch.float16, torch.float32])
+def test_condition_movie_hot_pixels(mc, dev, dtype):
+    """gain -> hot pixels -> mean-zero (examples/ttMotion.py:90-199): the example's detection rule
+    exactly (count and positions), our deterministic replacement, the mean taken after it."""
+    g = torch.Generator().manual_seed(12)
+    t, h, w = 3, 96, 120
+    raw = (torch.rand(t, h, w, generator=g) * 20 + 20)
+    low = 250.0 if dtype == torch.uint8 else -200.0  # unsigned storage has no low outliers
+    for f, (y, x, v) in enumerate([(0, 0, 250.0), (50, 60, 240.0), (95, 119, low)]):
+        raw[f, y, x] = v          # corners and interior, above and below
+    raw[1, 50, 61] = 245.0         # two adjacent hot pixels: neither is the other's replacement
+    raw = raw.to(dtype)
+    gain = torch.rand(h, w, generator=g) * 0.2 + 0.9
+    got, counts = mc.condition_movie(raw.to(dev), gain.to(dev), hot_pixel_threshold=10.0, return_hot_counts=True)
+    x = raw.float().numpy().astype(np.float64) * gain.numpy().astype(np.float64)
+    fixed, ref_counts = _hot_pixel_reference(x, 10.0)
+    assert counts.cpu().tolist() == ref_counts and sum(ref_counts) == 4
+    ref = torch.from_numpy((fixed - fixed.mean(axis=(1, 2), keepdims=True)).astype(np.float32))
+    assert float((got.cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    assert float(got.mean(dim=(1, 2)).abs().max()) < 1e-4
+    # no hot pixel at a huge threshold: identical to the plain conditioning
+    a = mc.condition_movie(raw.to(dev), gain.to(dev), hot_pixel_threshold=1e6)
+    b = mc.condition_movie(raw.to(dev), gain.to(dev))
+    assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+    # without mean-zero the untouched pixels are raw * gain exactly
+    c = mc.condition_movie(raw.to(dev), gain.to(dev), mean_zero=False, hot_pixel_threshold=10.0).cpu()
+    keep = torch.from_numpy(fixed == x)
+    assert torch.equal(c[keep], (raw.float() * gain)[keep])
+
+
+def test_evaluate_deformation_field_on_scattered_points(mc, dev):
+    """one launch for any set of points (the round-1 version launched once per distinct (t, y)):
+    both bases, points on the domain's edges, a leading batch shape, size-1 axes."""
+    g = torch.Generator().manual_seed(6)
+    for shape in ((2, 5, 4, 6), (2, 1, 3, 1), (3, 4, 1, 1)):
+        field = torch.randn(*shape, generator=g)
+        tyx = torch.rand(7, 11, 3, generator=g)
+        tyx[0, 0] = 0.0
+        tyx[0, 1] = 1.0
+        tyx[0, 2] = torch.tensor([0.5, 0.0, 1.0])
+        for gt in ("catmull_rom", "bspline"):
+            got = mc.evaluate_deformation_field(field.to(dev), tyx.to(dev), gt).cpu()
+            ref = oracle.evaluate_deformation_field(field, tyx, gt)
+            assert got.shape == (7, 11, shape[0])
+            assert float((got - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))

@@ -84,24 +84,12 @@ def image_shifts_to_deformation_field(shifts, pixel_spacing, device=None):
 @_on_gpu
 def evaluate_deformation_field(deformation_field, tyx, grid_type="catmull_rom"):
     """(c,nt,nh,nw) spline grid evaluated at (...,3) tyx points in [0,1] -> (...,c)
-    (deformation_field_utils.py:9-39).  Points are evaluated one tensor-product row at
-    a time through the lattice kernel (a 1x1x1 lattice per point)."""
+    (deformation_field_utils.py:9-39): one launch over all points (mc_spline_points)."""
     out_dev = deformation_field.device
     dev = require_gpu(out_dev)
     field = _stage(deformation_field, dev)
-    pts = tyx.detach().to(torch.float32).cpu().reshape(-1, 3)
-    lead = tyx.shape[:-1]
-    c = field.shape[0]
-    # group points that share (t, y): evaluate all their x at once
-    vals = torch.empty((pts.shape[0], c), dtype=torch.float32, device=dev)
-    keys = pts[:, :2].contiguous()
-    uniq, inverse = torch.unique(keys, dim=0, return_inverse=True)
-    for k in range(uniq.shape[0]):
-        sel = torch.nonzero(inverse == k).flatten()
-        lat = engine.spline_lattice(field, uniq[k, 0:1], uniq[k, 1:2], pts[sel, 2].contiguous(),
-                                    grid_type)  # (c,1,1,n)
-        vals[sel.to(dev)] = lat[:, 0, 0, :].transpose(0, 1)
-    return vals.reshape(*lead, c).to(out_dev)
+    vals = engine.spline_points(field, tyx.reshape(-1, 3), grid_type)
+    return vals.reshape(*tyx.shape[:-1], field.shape[0]).to(out_dev)
 
 
 @_on_gpu
@@ -345,16 +333,25 @@ def motion_correct_sum(image, deformation_grid, pixel_spacing, grid_type="catmul
 
 
 @_on_gpu
-def condition_movie(movie, gain=None, mean_zero=True, device=None):
+def condition_movie(movie, gain=None, mean_zero=True, device=None, hot_pixel_threshold=None,
+                    return_hot_counts=False):
     """Raw detector frames -> the fp32 stack the estimators expect: ``movie * gain`` (a (h,w)
     multiplicative gain reference, already flipped / rotated as needed) and, per frame,
     minus its own mean -- the ``gain_correct`` and ``set_frames_mean_zero`` steps of the
     reference's pipeline (examples/ttMotion.py:90-121, 174-199) done on the device straight
-    from uint8 / int16 / float16 / float32 storage.  (The example's hot-pixel step replaces
-    outliers by a RANDOM neighbour and has no deterministic counterpart here.)"""
+    from uint8 / int16 / float16 / float32 storage.  `hot_pixel_threshold` (the example's
+    ``remove_hot_pixels`` uses 10.0; None = off) adds that step between the two: a pixel more than
+    `threshold` standard deviations from its frame's mean is hot -- the example's detection -- and
+    is replaced by the mean of its neighbours that are not hot (the example draws a RANDOM
+    neighbour: that part has no deterministic counterpart and the rule here is ours).
+    `return_hot_counts`: also the (t,) int32 number of hot pixels found per frame."""
     out_dev = _out_device(movie, device)
     dev = require_gpu(out_dev)
-    return engine.condition_movie(movie.detach().to(dev), gain, bool(mean_zero)).to(out_dev)
+    res = engine.condition_movie(movie.detach().to(dev), gain, bool(mean_zero), hot_pixel_threshold,
+                                 bool(return_hot_counts))
+    if return_hot_counts:
+        return res[0].to(out_dev), res[1].to(out_dev)
+    return res.to(out_dev)
 
 
 @_on_gpu

@@ -289,6 +289,100 @@ __global__ __launch_bounds__(256) void cond_vec_kernel(const void* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------ hot pixels
+// The example pipeline's remove_hot_pixels (examples/ttMotion.py:127-172) sits between the gain
+// multiply and the mean-zero step: per frame, a pixel of v = raw * gain is hot when
+// v > mean + thr * std or v < mean - thr * std (numpy mean / population std of the whole frame).
+// That DETECTION is deterministic and is reproduced; the example then overwrites each hot pixel
+// with a RANDOM one of its neighbours (np.random.choice, in place, so the result also depends on
+// the visiting order): no deterministic counterpart exists.  Our rule: the mean of the (up to 8)
+// neighbours that are not hot themselves, taken from the frame BEFORE any replacement; the frame
+// mean if every neighbour is hot.  The per-frame mean subtracted afterwards is the mean AFTER the
+// replacement, as in the example's order of steps.
+template <int KIND>
+__global__ __launch_bounds__(256) void cond_stats2_kernel(const void* __restrict__ raw,
+                                                          const float* __restrict__ gain, int64_t hw,
+                                                          double* __restrict__ stats /* [f][3] */) {
+  const int f = blockIdx.y;
+  const int64_t base = (int64_t)f * hw;
+  double s = 0.0, q = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (int64_t)gridDim.x * 256) {
+    const double v = (double)(cond_load<KIND>(raw, base + i) * (gain ? gain[i] : 1.f));
+    s += v;
+    q += v * v;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_down(s, off);
+    q += __shfl_down(q, off);
+  }
+  __shared__ double part[2][4];
+  if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = s; part[1][threadIdx.x >> 6] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&stats[3 * f], (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]));
+    atomicAdd(&stats[3 * f + 1], (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]));
+  }
+}
+
+struct HotLimits {
+  float lo, hi, mean;
+};
+__device__ __forceinline__ HotLimits hot_limits(const double* stats, int f, int64_t hw, float thr) {
+  const double m = stats[3 * f] / (double)hw;
+  double var = stats[3 * f + 1] / (double)hw - m * m;
+  var = var > 0 ? var : 0;
+  const double sd = sqrt(var);
+  return HotLimits{(float)(m - (double)thr * sd), (float)(m + (double)thr * sd), (float)m};
+}
+
+// value of a hot pixel's replacement (see above); (y, x) inside the frame
+template <int KIND>
+__device__ __forceinline__ float hot_replacement(const void* raw, const float* gain, int64_t base, int h,
+                                                 int w, int y, int x, const HotLimits L) {
+  float acc = 0.f;
+  int n = 0;
+  for (int dy = -1; dy <= 1; ++dy)
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int yy = y + dy, xx = x + dx;
+      if ((dy | dx) == 0 || yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+      const int64_t j = (int64_t)yy * w + xx;
+      const float v = cond_load<KIND>(raw, base + j) * (gain ? gain[j] : 1.f);
+      if (v > L.hi || v < L.lo) continue;
+      acc += v;
+      ++n;
+    }
+  return n ? acc / (float)n : L.mean;
+}
+
+// MODE 0: find the hot pixels, accumulate sum(replacement - value) and their number per frame;
+// MODE 1: write out = (hot ? replacement : value) - mean_after.
+template <int KIND, int MODE>
+__global__ __launch_bounds__(256) void cond_hot_kernel(const void* __restrict__ raw,
+                                                       const float* __restrict__ gain, int h, int w,
+                                                       float thr, int mean_zero, double* __restrict__ stats,
+                                                       int* __restrict__ hot_count, float* __restrict__ out) {
+  const int f = blockIdx.y;
+  const int64_t hw = (int64_t)h * w, base = (int64_t)f * hw;
+  const HotLimits L = hot_limits(stats, f, hw, thr);
+  const float mean_after = (MODE == 1 && mean_zero) ? (float)((stats[3 * f] + stats[3 * f + 2]) / (double)hw) : 0.f;
+  double delta = 0.0;
+  int cnt = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (int64_t)gridDim.x * 256) {
+    float v = cond_load<KIND>(raw, base + i) * (gain ? gain[i] : 1.f);
+    if (v > L.hi || v < L.lo) {
+      const int y = (int)(i / w), x = (int)(i - (int64_t)y * w);
+      const float r = hot_replacement<KIND>(raw, gain, base, h, w, y, x, L);
+      if (MODE == 0) { delta += (double)r - (double)v; ++cnt; }
+      v = r;
+    }
+    if (MODE == 1) out[base + i] = v - mean_after;
+  }
+  if (MODE == 0 && cnt) {  // rare: a handful of pixels per frame
+    atomicAdd(&stats[3 * f + 2], delta);
+    if (hot_count) atomicAdd(&hot_count[f], cnt);
+  }
+}
+
 // ------------------------------------------------------------------ statistics
 template <typename T>
 __global__ __launch_bounds__(256) void box_stats_partial(const T* __restrict__ stack, int h,
@@ -434,6 +528,40 @@ int mc_dose_accumulate(const void* S, int nframes, int frame0, int total_frames,
   hipLaunchKernelGGL(dose_accumulate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, (const float2*)S, nframes, frame0, total_frames, (float2*)A, W,
                      H, nkx, pixel_size, pre_exposure, dose_per_frame, vscale, first, last);
+  return mc_check_launch();
+}
+
+int mc_condition_movie_hot(const void* raw, int kind, const float* gain, int nframes, int h, int w,
+                           int mean_zero, float threshold, double* stats, int* hot_count, float* out,
+                           void* stream) {
+  if (!raw || !out || !stats || nframes < 1 || h < 1 || w < 1 || kind < 0 || kind > 3 || !(threshold > 0.f))
+    return MC_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t hw = (int64_t)h * w;
+  hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 3 * nframes, st);
+  if (e != hipSuccess) return (int)e;
+  if (hot_count) {
+    e = hipMemsetAsync(hot_count, 0, sizeof(int) * nframes, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  int64_t blocks = (hw + 256 * 8 - 1) / (256 * 8);
+  if (blocks > 2048) blocks = 2048;
+  dim3 grid((unsigned)blocks, nframes);
+#define MC_HOT(K)                                                                                        \
+  do {                                                                                                   \
+    hipLaunchKernelGGL(cond_stats2_kernel<K>, grid, dim3(256), 0, st, raw, gain, hw, stats);             \
+    hipLaunchKernelGGL((cond_hot_kernel<K, 0>), grid, dim3(256), 0, st, raw, gain, h, w, threshold,      \
+                       mean_zero, stats, hot_count, (float*)nullptr);                                    \
+    hipLaunchKernelGGL((cond_hot_kernel<K, 1>), grid, dim3(256), 0, st, raw, gain, h, w, threshold,      \
+                       mean_zero, stats, (int*)nullptr, out);                                            \
+  } while (0)
+  switch (kind) {
+    case 0: MC_HOT(0); break;
+    case 1: MC_HOT(1); break;
+    case 2: MC_HOT(2); break;
+    default: MC_HOT(3); break;
+  }
+#undef MC_HOT
   return mc_check_launch();
 }
 

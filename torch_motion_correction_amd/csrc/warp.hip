@@ -1886,6 +1886,33 @@ __global__ void spline_lattice_kernel(const float* __restrict__ data, int c, int
   out[i] = vt;
 }
 
+// Spline grid at scattered points: per point 3 x 4 taps (host tables, as for the lattice); same
+// summation order as spline_lattice_kernel.  out[i][ch].
+__global__ void spline_points_kernel(const float* __restrict__ data, int c, int nt, int nh, int nw,
+                                     const int* __restrict__ idx_t, const float* __restrict__ w_t,
+                                     const int* __restrict__ idx_y, const float* __restrict__ w_y,
+                                     const int* __restrict__ idx_x, const float* __restrict__ w_x,
+                                     int64_t npoints, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npoints * c) return;
+  const int64_t pt = i / c;
+  const int ch = (int)(i - pt * c);
+  const float* d = data + (int64_t)ch * nt * nh * nw;
+  float vt = 0.f;
+  for (int kt = 0; kt < 4; ++kt) {
+    const float* dt = d + (int64_t)idx_t[4 * pt + kt] * nh * nw;
+    float vy = 0.f;
+    for (int ky = 0; ky < 4; ++ky) {
+      const float* dy = dt + (int64_t)idx_y[4 * pt + ky] * nw;
+      float vx = 0.f;
+      for (int kx = 0; kx < 4; ++kx) vx += dy[idx_x[4 * pt + kx]] * w_x[4 * pt + kx];
+      vy += vx * w_y[4 * pt + ky];
+    }
+    vt += vy * w_t[4 * pt + kt];
+  }
+  out[i] = vt;
+}
+
 static int64_t field_flag_bytes(int nframes, int h, int w) {
   const int64_t tx = (w + RIGID_LANES * 4 - 1) / (RIGID_LANES * 4);
   const int64_t ty = (h + RIGID_WAVES * RIGID_ROWS - 1) / (RIGID_WAVES * RIGID_ROWS);
@@ -1907,6 +1934,17 @@ int mc_spline_lattice(const float* data, int c, int nt, int nh, int nw, const in
   hipLaunchKernelGGL(spline_lattice_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, data, c, nt, nh, nw, idx_t, w_t, NT, idx_y, w_y, NY,
                      idx_x, w_x, NX, out);
+  return mc_check_launch();
+}
+
+int mc_spline_points(const float* data, int c, int nt, int nh, int nw, const int* idx_t, const float* w_t,
+                     const int* idx_y, const float* w_y, const int* idx_x, const float* w_x, int64_t npoints,
+                     float* out, void* stream) {
+  if (!data || !idx_t || !w_t || !idx_y || !w_y || !idx_x || !w_x || !out) return MC_ERR_ARG;
+  if (c < 1 || nt < 1 || nh < 1 || nw < 1 || npoints < 1) return MC_ERR_ARG;
+  const int64_t total = npoints * c;
+  hipLaunchKernelGGL(spline_points_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, data, c, nt, nh, nw, idx_t, w_t, idx_y, w_y, idx_x, w_x, npoints, out);
   return mc_check_launch();
 }
 

@@ -430,6 +430,25 @@ def spline_lattice(field, ut, uy, ux, grid_type):
     return out
 
 
+def spline_points(field, tyx, grid_type):
+    """Evaluate the (c,nt,nh,nw) spline grid at (n, 3) points (t, y, x in [0,1], CPU float32) ->
+    (n, c) on the device: ONE launch (tap tables per point built on the host)."""
+    lib = _lib.load()
+    dev = field.device
+    c, nt, nh, nw = field.shape
+    pts = tyx.detach().to(torch.float32).cpu().reshape(-1, 3)
+    n = int(pts.shape[0])
+    out = torch.empty((n, c), dtype=torch.float32, device=dev)
+    if n == 0:
+        return out
+    tabs = [spline.axis_taps(size, pts[:, a].contiguous(), grid_type) for a, size in enumerate((nt, nh, nw))]
+    dt = [(i.to(dev), w.to(dev)) for i, w in tabs]
+    f = field.contiguous()
+    check(lib.mc_spline_points(ptr(f), c, nt, nh, nw, ptr(dt[0][0]), ptr(dt[0][1]), ptr(dt[1][0]), ptr(dt[1][1]),
+                               ptr(dt[2][0]), ptr(dt[2][1]), n, ptr(out), stream_ptr(dev)), "mc_spline_points")
+    return out
+
+
 def frame_lattices(field, t, grid_type):
     """(t, 2, 10gh, 10gw) Angstrom lattices, one per frame time linspace(0,1,t)
     (correct_motion.py:57,67-72)."""
@@ -729,9 +748,11 @@ def dose_weighted_sum(img, pixel_spacing, dose_per_frame, pre_exposure=0.0, volt
 _RAW_KINDS = {torch.uint8: 0, torch.int16: 1, torch.float16: 2, torch.float32: 3}
 
 
-def condition_movie(raw, gain=None, mean_zero=True):
+def condition_movie(raw, gain=None, mean_zero=True, hot_pixel_threshold=None, return_hot_counts=False):
     """raw (t,h,w) u8 / i16 / f16 / f32 on the GPU -> fp32 frames: x * gain, minus the frame's
-    own mean (examples/ttMotion.py:90-121, 174-199), in two passes over the raw bytes."""
+    own mean (examples/ttMotion.py:90-121, 174-199), in two passes over the raw bytes.  With
+    `hot_pixel_threshold` (the example uses 10.0) the hot-pixel step of examples/ttMotion.py:127-172
+    runs in between: the example's detection, a deterministic replacement (mc_condition_movie_hot)."""
     lib = _lib.load()
     if raw.dtype not in _RAW_KINDS:
         raise TypeError(f"unsupported raw frame type {raw.dtype}; use uint8, int16, float16 or float32")
@@ -743,10 +764,17 @@ def condition_movie(raw, gain=None, mean_zero=True):
             raise ValueError(f"gain reference has shape {tuple(gain.shape)}, frames are {(h, w)}")
         gain = gain.to(device=dev, dtype=torch.float32).contiguous()
     out = torch.empty((t, h, w), dtype=torch.float32, device=dev)
+    if hot_pixel_threshold is not None:
+        stats = torch.empty(3 * t, dtype=torch.float64, device=dev)
+        counts = torch.empty(t, dtype=torch.int32, device=dev)
+        check(lib.mc_condition_movie_hot(ptr(raw), _RAW_KINDS[raw.dtype], ptr(gain), t, h, w,
+                                         1 if mean_zero else 0, float(hot_pixel_threshold), ptr(stats),
+                                         ptr(counts), ptr(out), stream_ptr(dev)), "mc_condition_movie_hot")
+        return (out, counts) if return_hot_counts else out
     sums = torch.empty(t, dtype=torch.float64, device=dev) if mean_zero else None
     check(lib.mc_condition_movie(ptr(raw), _RAW_KINDS[raw.dtype], ptr(gain), t, h * w, 1 if mean_zero else 0,
                                  ptr(sums), ptr(out), stream_ptr(dev)), "mc_condition_movie")
-    return out
+    return (out, torch.zeros(t, dtype=torch.int32, device=dev)) if return_hot_counts else out
 
 
 def sum_frames(frames):
