@@ -16,4 +16,4 @@ for mb in (8, 16, 32, 64, 96, 128, 192, 256, 512, 1024, 2048):
     t_copy = timeit(lambda: b.copy_(a))
     t_read = timeit(lambda: torch.max(a))  # read-only reduction
     t_fill = timeit(lambda: b.fill_(1.0))
-    print(f"{mb:5d} MiB  copy {2*mb/1024/t_copy*1e3*1.048576:7.2f} TB/s(r+w)   max {mb/1024/t_read*1e3*1.048576:7.2f} TB/s(r)   fill {mb/1024/t_fill*1e3*1.048576:7.2f} TB/s(w)", flush=True)
+    print(f"{mb:5d} MiB  copy {2*mb/1024/t_copy*1e3*1.048576:7.2f} GB/s (r+w)   max {mb/1024/t_read*1e3*1.048576:7.2f} GB/s (r)   fill {mb/1024/t_fill*1e3*1.048576:7.2f} GB/s (w)", flush=True)
