@@ -555,7 +555,45 @@ def test_pruned_spectrum_on_arbitrary_sizes(dev, h, w, pruned_m):
     assert float((S - sub).abs().max() / sub.abs().max()) <= 5e-6
 
 
-@pytest.mark.parametrize("shape", [(3, 100, 66), (2, 96, 120), (2, 64, 90), (2, 77, 64)])
+@pytest.mark.parametrize("t,h,w", [(3, 96, 5760), (2, 64, 11520), (3, 2880, 128), (2, 96, 7000), (2, 5760, 64)])
+def test_mixed_radix_lines(mc, dev, t, h, w):
+    """Rows of 5760 / 11520 columns (K3 detectors) and columns of 2880 / 5760 rows are transformed
+    DIRECTLY by radix-8/5/3 passes (n = 2880 = 2^6 3^2 5, 5760 = 2^7 3^2 5) instead of chirp-z; 7000
+    columns take a chirp-z line of M = 5120 = 2^10 5.  The integer shifts must equal the oracle's,
+    the pruned spectra the chirp-z path's and torch's."""
+    from torch_motion_correction_amd import engine, plan
+
+    st, _, _ = drift_stack(t, h, w, seed=h + w)
+    got = mc.estimate_global_motion(st.to(dev), 1.0).cpu()
+    ref, ccs = oracle.estimate_global_motion(st, 1.0, return_cc=True)
+    for f, cc in ccs.items():
+        top = torch.topk(cc.flatten(), 2).values
+        if float(top[0] - top[1]) > 1e-5 * float(top[0].abs()):
+            assert torch.equal(got[:, f], ref[:, f]), (f, got[:, f].flatten(), ref[:, f].flatten())
+    pl = plan.get_xc_plan(h, w, 1.0, 500.0, (300, 10), dev)
+    gm = pl.geom
+    d = st.to(dev)
+    off = torch.arange(t, device=dev, dtype=torch.int64) * (h * w)
+    S = torch.view_as_complex(engine._forward_spectra(d, off, w, None, pl, engine.central_box_stats(d)).cpu())
+    spec = (torch.fft.rfftn(oracle.normalize_image(st) * tp.circle(min(h, w) / 4, (h, w), smoothing_radius=min(h, w) / 8),
+                            dim=(-2, -1)) * oracle.prepare_bandpass_filter((300, 10), (h, w), 1.0)
+            * tp.b_envelope(500, (h, w), 1.0))
+    rows = list(range(gm.kyp)) + list(range(h - gm.kyn, h))
+    sub = spec[:, rows][:, :, : gm.nkx].transpose(1, 2)
+    assert float((S - sub).abs().max() / sub.abs().max()) <= 5e-6
+    if w // 2 in plan.DIRECT_LINE_LENGTHS or h in plan.DIRECT_LINE_LENGTHS:
+        try:
+            plan.USE_DIRECT_LINES = False
+            plan._LINES.clear()
+            S2 = torch.view_as_complex(engine._forward_spectra(d, off, w, None, pl, engine.central_box_stats(d)).cpu())
+        finally:
+            plan.USE_DIRECT_LINES = True
+            plan._LINES.clear()
+        assert float((S - S2).abs().max() / sub.abs().max()) <= 5e-6
+
+
+@pytest.mark.parametrize("shape", [(3, 100, 66), (2, 96, 120), (2, 64, 90), (2, 77, 64), (2, 64, 5760),
+                                   (2, 2880, 64)])
 def test_correct_motion_fast_on_arbitrary_sizes(mc, dev, shape):
     g = torch.Generator().manual_seed(sum(shape))
     img = torch.randn(*shape, generator=g)

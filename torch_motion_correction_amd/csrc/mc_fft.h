@@ -323,6 +323,134 @@ __device__ __forceinline__ void wg_fft_inplace(cfloat* line, int tid, const cflo
   fft_rec<N, 1, DIR, true, true>(line, tid, tw, tw_stride, load, store);
 }
 
+// =====================================================================================
+// Lengths N = 2^a 3^b 5^c ("smooth": 2880 and 5760 = half the 5760- and 11520-column rows of
+// K3 detectors, 5120 and 10240 as chirp-z lengths): the same one-line Stockham scheme as above
+// with radix-3 and radix-5 passes and sub-transform lengths that are no longer powers of two
+// (k = j mod NS instead of a mask).  Radices: 8 while N allows, then 4, 5, 3, 2.
+// tw = exp(-2 pi i k / (N tw_stride)).
+// =====================================================================================
+template <int DIR>
+__device__ __forceinline__ void bfly3(cfloat* a) {
+  const float s = 0.86602540378443864676f;
+  const cfloat t1 = cadd(a[1], a[2]);
+  const cfloat t2 = cmake(a[0].x - 0.5f * t1.x, a[0].y - 0.5f * t1.y);
+  const cfloat d = cmul_i<DIR>(cscale(csub(a[1], a[2]), s));  // (-/+ i) s (a1 - a2)
+  a[0] = cadd(a[0], t1);
+  a[1] = cadd(t2, d);
+  a[2] = csub(t2, d);
+}
+
+template <int DIR>
+__device__ __forceinline__ void bfly5(cfloat* a) {
+  const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+  const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+  const cfloat a1 = cadd(a[1], a[4]), a2 = cadd(a[2], a[3]);
+  const cfloat b1 = csub(a[1], a[4]), b2 = csub(a[2], a[3]);
+  const cfloat m1 = cmake(a[0].x + c1 * a1.x + c2 * a2.x, a[0].y + c1 * a1.y + c2 * a2.y);
+  const cfloat m2 = cmake(a[0].x + c2 * a1.x + c1 * a2.x, a[0].y + c2 * a1.y + c1 * a2.y);
+  const cfloat n1 = cmul_i<DIR>(cmake(s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y));
+  const cfloat n2 = cmul_i<DIR>(cmake(s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y));
+  a[0] = cadd(a[0], cadd(a1, a2));
+  a[1] = cadd(m1, n1);
+  a[4] = csub(m1, n1);
+  a[2] = cadd(m2, n2);
+  a[3] = csub(m2, n2);
+}
+
+template <int R, int DIR>
+__device__ __forceinline__ void bfly_any(cfloat* a) {
+  if constexpr (R == 5) bfly5<DIR>(a);
+  else if constexpr (R == 3) bfly3<DIR>(a);
+  else bfly<R, DIR>(a);
+}
+
+__host__ __device__ constexpr int smooth_radix(int rem) {
+  return rem % 8 == 0 ? 8 : rem % 4 == 0 ? 4 : rem % 5 == 0 ? 5 : rem % 3 == 0 ? 3 : rem % 2 == 0 ? 2 : 0;
+}
+__host__ __device__ constexpr bool is_smooth(int n) {
+  while (n % 2 == 0) n /= 2;
+  while (n % 3 == 0) n /= 3;
+  while (n % 5 == 0) n /= 5;
+  return n == 1;
+}
+
+template <int N, int R, int NS, int DIR, bool SYNC_MID, bool SYNC_END, typename Load, typename Store>
+__device__ __forceinline__ void smooth_pass(int tid, const cfloat* __restrict__ tw, int tw_stride,
+                                            Load load, Store store) {
+  constexpr int NB = N / R;
+  constexpr int IT = (NB + MC_WG - 1) / MC_WG;
+  cfloat v[IT][R];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int j = tid + it * MC_WG;
+    if (j < NB) {
+#pragma unroll
+      for (int m = 0; m < R; ++m) v[it][m] = load(j + m * NB);
+      if constexpr (NS > 1) {
+        const int k = j % NS;
+        cfloat w1 = tw[k * (N / (NS * R)) * tw_stride];
+        if (DIR > 0) w1.y = -w1.y;
+        cfloat wm = w1;
+#pragma unroll
+        for (int m = 1; m < R; ++m) {
+          v[it][m] = cmul(v[it][m], wm);
+          if (m + 1 < R) wm = cmul(wm, w1);
+        }
+      }
+      bfly_any<R, DIR>(v[it]);
+    }
+  }
+  if (SYNC_MID) __syncthreads();
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int j = tid + it * MC_WG;
+    if (j < NB) {
+      const int k = j % NS;
+      const int base = (j - k) * R + k;
+#pragma unroll
+      for (int m = 0; m < R; ++m) store(base + m * NS, v[it][m]);
+    }
+  }
+  if (SYNC_END) __syncthreads();
+}
+
+template <int N, int NS, int DIR, bool FIRST, bool FIRST_LDS = false, typename Load, typename Store>
+__device__ __forceinline__ void smooth_rec(cfloat* line, int tid, const cfloat* __restrict__ tw,
+                                           int tw_stride, Load load, Store store) {
+  constexpr int R = smooth_radix(N / NS);
+  static_assert(R > 0, "length is not of the form 2^a 3^b 5^c");
+  constexpr bool LAST = (NS * R == N);
+  auto lds_load = [line](int i) { return line[lpad(i)]; };
+  auto lds_store = [line](int i, cfloat v) { line[lpad(i)] = v; };
+  if constexpr (FIRST && LAST) {
+    smooth_pass<N, R, NS, DIR, FIRST_LDS, false>(tid, tw, tw_stride, load, store);
+  } else if constexpr (FIRST) {
+    smooth_pass<N, R, NS, DIR, FIRST_LDS, true>(tid, tw, tw_stride, load, lds_store);
+    smooth_rec<N, NS * R, DIR, false>(line, tid, tw, tw_stride, load, store);
+  } else if constexpr (LAST) {
+    smooth_pass<N, R, NS, DIR, true, false>(tid, tw, tw_stride, lds_load, store);
+  } else {
+    smooth_pass<N, R, NS, DIR, true, true>(tid, tw, tw_stride, lds_load, lds_store);
+    smooth_rec<N, NS * R, DIR, false>(line, tid, tw, tw_stride, load, store);
+  }
+}
+
+// Length-N transform (any N = 2^a 3^b 5^c; powers of two take the plan-driven passes above) by
+// the whole workgroup; contract as wg_fft.
+template <int N, int DIR, typename Load, typename Store>
+__device__ __forceinline__ void wg_fft_any(cfloat* line, int tid, const cfloat* __restrict__ tw,
+                                           int tw_stride, Load load, Store store) {
+  if constexpr ((N & (N - 1)) == 0) fft_rec<N, 1, DIR, true>(line, tid, tw, tw_stride, load, store);
+  else smooth_rec<N, 1, DIR, true>(line, tid, tw, tw_stride, load, store);
+}
+template <int N, int DIR, typename Load, typename Store>
+__device__ __forceinline__ void wg_fft_any_inplace(cfloat* line, int tid, const cfloat* __restrict__ tw,
+                                                   int tw_stride, Load load, Store store) {
+  if constexpr ((N & (N - 1)) == 0) fft_rec<N, 1, DIR, true, true>(line, tid, tw, tw_stride, load, store);
+  else smooth_rec<N, 1, DIR, true, true>(line, tid, tw, tw_stride, load, store);
+}
+
 // Bluestein chirp-z: a length-n DFT (any n, 2n-1 <= M = power of two) of x as
 //   X[k] = c[k] * ( (x .* c) (*) conj(c) )[k],   c[j] = exp(DIR * i*pi*j^2/n)
 // with the convolution done by two length-M transforms in `line`.  chirp = c for this
@@ -341,7 +469,7 @@ __device__ __forceinline__ void wg_bluestein(cfloat* line, int tid, const cfloat
                                              Store store, int keep = 0) {
   auto in1 = [&](int j) { return j < n ? cmul(load(j), chirp[j]) : cmake(0.f, 0.f); };
   auto out1 = [&](int j, cfloat v) { line[lpad(j)] = cmul(v, bspec[j]); };
-  wg_fft<M, -1>(line, tid, tw_m, 1, in1, out1);
+  wg_fft_any<M, -1>(line, tid, tw_m, 1, in1, out1);
   __syncthreads();
   auto in2 = [&](int j) { return line[lpad(j)]; };
   auto out2 = [&](int p, cfloat v) {
@@ -356,7 +484,7 @@ __device__ __forceinline__ void wg_bluestein(cfloat* line, int tid, const cfloat
     }
     if (k < n) store(k, cmul(v, chirp[k]));
   };
-  wg_fft_inplace<M, +1>(line, tid, tw_m, 1, in2, out2);
+  wg_fft_any_inplace<M, +1>(line, tid, tw_m, 1, in2, out2);
 }
 
 // =====================================================================================

@@ -1964,6 +1964,20 @@ __global__ __launch_bounds__(MC_WG) void xcg_peak_nbhd(const cfloat* __restrict_
 // 4092 x 5760).  Tables per (n, direction): chirp[n] = exp(-+ i pi j^2 / n),
 // bspec[M] = FFT_M(wrapped conj chirp) / M  (host, double precision, plan.py).
 // =====================================================================================
+// Line-engine codes of the xcg_* kernels' template parameter: 5..14 = chirp-z on M = 2^code points;
+// 20 / 21 = chirp-z on M = 5120 / 10240 (2^k 5); 22 / 23 = NO chirp, a direct mixed-radix transform
+// of the n = 2880 / 5760 = 2^a 3^2 5 points themselves (rows of 5760 / 11520 columns).
+__host__ __device__ constexpr int mc_line_m(int code) {
+  return code < 20 ? (1 << code) : code == 20 ? 5120 : code == 21 ? 10240 : code == 22 ? 2880 : code == 23 ? 5760 : 0;
+}
+__host__ __device__ constexpr bool mc_line_direct(int code) { return code >= 22; }
+static int mc_line_code(int M, bool direct) {
+  if (direct) return M == 2880 ? 22 : M == 5760 ? 23 : -1;
+  if (M == 5120) return 20;
+  if (M == 10240) return 21;
+  return mc_is_pow2(M) ? mc_ilog2(M) : -1;
+}
+
 struct XcLine {
   const cfloat* tw_m;   // exp(-2 pi i k / M), M entries
   const cfloat* chirp;  // n entries
@@ -1972,13 +1986,25 @@ struct XcLine {
   int keep;             // > 0: output-pruned plan (wg_bluestein), only xcg_rows_fwd takes it
 };
 
+// One line transform of the xcg_* kernels: chirp-z on M points (tables of `ln`), or -- for the
+// direct codes -- the mixed-radix transform of the n = M points themselves (ln.tw_m then holds
+// exp(-2 pi i k / n)); DIR only matters for the direct form (the chirp tables carry the direction).
+template <int CODE, int DIR, typename Load, typename Store>
+__device__ __forceinline__ void xcg_line_fft(cfloat* line, int tid, const XcLine& ln, int n, Load load,
+                                             Store store, int keep = 0) {
+  constexpr int M = mc_line_m(CODE);
+  if constexpr (mc_line_direct(CODE)) wg_fft_any<M, DIR>(line, tid, ln.tw_m, 1, load, store);
+  else wg_bluestein<M>(line, tid, ln.tw_m, ln.chirp, ln.bspec, n, load, store, keep);
+}
+
+
 template <int LOGM>
 __global__ __launch_bounds__(MC_WG) void xcg_rows_fwd(
     const float* __restrict__ src, const int64_t* __restrict__ job_off, int64_t row_stride,
     const int* __restrict__ job_expo, const float* __restrict__ mask,
     const float* __restrict__ mean_rstd, cfloat* __restrict__ T1,
     const cfloat* __restrict__ tw_row, XcLine ln, XcGeom g) {
-  constexpr int M = 1 << LOGM;
+  constexpr int M = mc_line_m(LOGM);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cfloat* line = reinterpret_cast<cfloat*>(smem);
   cfloat* zlo = line + lds_len(M);       // Z[k], k < nkx
@@ -2012,7 +2038,7 @@ __global__ __launch_bounds__(MC_WG) void xcg_rows_fwd(
       auto store1 = [&](int k, cfloat v) {
         if (k < g.nkx) stg[k * (RG + 1) + r] = v;
       };
-      wg_bluestein<M>(line, tid, ln.tw_m, ln.chirp, ln.bspec, n, load1, store1, ln.keep);
+      xcg_line_fft<LOGM, -1>(line, tid, ln, n, load1, store1, ln.keep);
       __syncthreads();
       continue;
     }
@@ -2035,7 +2061,7 @@ __global__ __launch_bounds__(MC_WG) void xcg_rows_fwd(
       if (k < g.nkx) zlo[k] = v;
       if (k > 0 && n - k <= g.nkx) zhi[n - k] = v;
     };
-    wg_bluestein<M>(line, tid, ln.tw_m, ln.chirp, ln.bspec, n, load, store, ln.keep);
+    xcg_line_fft<LOGM, -1>(line, tid, ln, n, load, store, ln.keep);
     __syncthreads();
     for (int k = tid; k < g.nkx; k += MC_WG) {
       const cfloat zk = (k < n) ? zlo[k] : zlo[0];                  // Z[n] == Z[0]
@@ -2064,7 +2090,7 @@ template <int LOGM>
 __global__ __launch_bounds__(MC_WG) void xcg_cols_fwd(const cfloat* __restrict__ T1,
                                                       const float* __restrict__ filt,
                                                       cfloat* __restrict__ S, XcLine ln, XcGeom g) {
-  constexpr int M = 1 << LOGM;
+  constexpr int M = mc_line_m(LOGM);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cfloat* line = reinterpret_cast<cfloat*>(smem);
   const int tid = threadIdx.x;
@@ -2081,7 +2107,7 @@ __global__ __launch_bounds__(MC_WG) void xcg_cols_fwd(const cfloat* __restrict__
     const int kyi = kept_index(ky, H, g.kyp, g.kyn);
     if (kyi >= 0) out[kyi] = f ? cscale(v, f[kyi]) : v;
   };
-  wg_bluestein<M>(line, tid, ln.tw_m, ln.chirp, ln.bspec, H, load, store);
+  xcg_line_fft<LOGM, -1>(line, tid, ln, H, load, store);
 }
 
 // MODE 0: conj(ref)*cur; MODE 1: cur * exp(-2 pi i (fy sy + fx sx)) (Fourier shift)
@@ -2090,7 +2116,7 @@ __global__ __launch_bounds__(MC_WG) void xcg_cols_inv(
     const cfloat* __restrict__ S_cur, const int* __restrict__ cur_idx,
     const cfloat* __restrict__ S_ref, const int* __restrict__ ref_idx,
     const float* __restrict__ shifts, cfloat* __restrict__ T2, float scale, XcLine ln, XcGeom g) {
-  constexpr int M = 1 << LOGM;
+  constexpr int M = mc_line_m(LOGM);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cfloat* line = reinterpret_cast<cfloat*>(smem);
   const int tid = threadIdx.x;
@@ -2123,7 +2149,7 @@ __global__ __launch_bounds__(MC_WG) void xcg_cols_inv(
     return cscale(v, scale);
   };
   auto store = [&](int y, cfloat v) { out[y] = v; };
-  wg_bluestein<M>(line, tid, ln.tw_m, ln.chirp, ln.bspec, H, load, store);
+  xcg_line_fft<LOGM, +1>(line, tid, ln, H, load, store);
 }
 
 template <int LOGM, int EPI>
@@ -2132,7 +2158,7 @@ __global__ __launch_bounds__(MC_WG) void xcg_rows_inv(
     float* __restrict__ part_val, int* __restrict__ part_idx, float* __restrict__ out_real,
     const int64_t* __restrict__ out_off, int64_t out_stride, const cfloat* __restrict__ tw_row,
     XcLine ln, XcGeom g, int near, int phase) {
-  constexpr int M = 1 << LOGM;
+  constexpr int M = mc_line_m(LOGM);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cfloat* line = reinterpret_cast<cfloat*>(smem);
   cfloat* stg = line + lds_len(M);
@@ -2181,11 +2207,11 @@ __global__ __launch_bounds__(MC_WG) void xcg_rows_inv(
       };
       if constexpr (EPI == 0) {
         auto store1 = [&](int j, cfloat v) { cand_merge(bv, bi, v.x, y * g.W + j); };
-        wg_bluestein<M>(line, tid, ln.tw_m, ln.chirp, ln.bspec, n, load1, store1);
+        xcg_line_fft<LOGM, +1>(line, tid, ln, n, load1, store1);
       } else {
         float* orow = out_real + out_off[p] + (int64_t)y * out_stride;
         auto store1 = [&](int j, cfloat v) { orow[j] = v.x; };
-        wg_bluestein<M>(line, tid, ln.tw_m, ln.chirp, ln.bspec, n, load1, store1);
+        xcg_line_fft<LOGM, +1>(line, tid, ln, n, load1, store1);
       }
       __syncthreads();
       continue;
@@ -2211,14 +2237,14 @@ __global__ __launch_bounds__(MC_WG) void xcg_rows_inv(
         cand_merge(bv, bi, v.x, flat);
         cand_merge(bv, bi, v.y, flat + 1);
       };
-      wg_bluestein<M>(line, tid, ln.tw_m, ln.chirp, ln.bspec, n, load, store);
+      xcg_line_fft<LOGM, +1>(line, tid, ln, n, load, store);
     } else {
       float* orow = out_real + out_off[p] + (int64_t)y * out_stride;
       auto store = [&](int j, cfloat v) {
         orow[2 * j] = v.x;
         orow[2 * j + 1] = v.y;
       };
-      wg_bluestein<M>(line, tid, ln.tw_m, ln.chirp, ln.bspec, n, load, store);
+      xcg_line_fft<LOGM, +1>(line, tid, ln, n, load, store);
     }
     __syncthreads();
   }
@@ -2256,6 +2282,10 @@ __global__ __launch_bounds__(MC_WG) void xcg_rows_inv(
     MC_DISPATCH_CASE(12, __VA_ARGS__)        \
     MC_DISPATCH_CASE(13, __VA_ARGS__)        \
     MC_DISPATCH_CASE(14, __VA_ARGS__)        \
+    MC_DISPATCH_CASE(20, __VA_ARGS__)        \
+    MC_DISPATCH_CASE(21, __VA_ARGS__)        \
+    MC_DISPATCH_CASE(22, __VA_ARGS__)        \
+    MC_DISPATCH_CASE(23, __VA_ARGS__)        \
     default:                                 \
       return MC_ERR_UNSUPPORTED;             \
   }
@@ -2282,16 +2312,21 @@ static int geom_from_g(const mc_xc_geom* q, XcGeom* g) {
 static int line_from(const mc_xc_line* l, int n, XcLine* out, int* logm, bool allow_keep = false,
                      int need_keep = 0) {
   if (!l || !l->tw_m || !l->chirp || !l->bspec) return MC_ERR_ARG;
-  if (!mc_is_pow2(l->M) || l->M < 32 || l->M > 16384) return MC_ERR_UNSUPPORTED;
+  // direct plan: M == n and n is one of the mixed-radix lengths -- no chirp, tw_m = exp(-2 pi i k / n)
+  const bool direct = l->M == n && l->keep == 0 && mc_line_code(n, true) >= 0;
+  const int code = mc_line_code(l->M, direct);
+  if (code < 0 || l->M < 32 || l->M > 16384) return MC_ERR_UNSUPPORTED;
   if (l->keep < 0 || (l->keep > 0 && !allow_keep)) return MC_ERR_ARG;
-  if (l->keep > 0) {
-    if (l->keep < need_keep || l->M < n + 2 * l->keep - 1) return MC_ERR_ARG;
-  } else if (l->M < 2 * n - 1) {
-    return MC_ERR_UNSUPPORTED;
+  if (!direct) {
+    if (l->keep > 0) {
+      if (l->keep < need_keep || l->M < n + 2 * l->keep - 1) return MC_ERR_ARG;
+    } else if (l->M < 2 * n - 1) {
+      return MC_ERR_UNSUPPORTED;
+    }
   }
   out->tw_m = (const cfloat*)l->tw_m; out->chirp = (const cfloat*)l->chirp;
   out->bspec = (const cfloat*)l->bspec; out->n = n; out->keep = l->keep;
-  *logm = mc_ilog2(l->M);
+  *logm = code;
   return MC_OK;
 }
 

@@ -144,10 +144,18 @@ def native_height(h: int) -> bool:
     return _is_pow2(h) and 16 <= h <= 4096
 
 
+DIRECT_LINE_LENGTHS = (2880, 5760)   # mixed-radix (2^a 3^2 5) lines transformed as they are: no chirp-z
+SMOOTH_CHIRP_LENGTHS = (5120, 10240)  # chirp-z lengths 2^k 5 next to the powers of two
+
+
 def bluestein_size_for(length: int) -> int:
+    """Smallest chirp-z length libmcorr has kernels for: a power of two, or 5120 / 10240."""
     m = 32
     while m < length:
         m *= 2
+    for c in SMOOTH_CHIRP_LENGTHS:
+        if length <= c < m:
+            m = c
     return m
 
 
@@ -156,6 +164,7 @@ def bluestein_size(n: int) -> int:
 
 
 _LINES: dict = {}
+USE_DIRECT_LINES = True  # tests: False forces chirp-z on the mixed-radix lengths too
 
 
 def line_plan(n: int, direction: int, device, keep: int = 0):
@@ -168,6 +177,14 @@ def line_plan(n: int, direction: int, device, keep: int = 0):
     convolution only touches offsets k - j in (-(n-1) - (keep-1) .. keep-1), so a circular
     length M >= n + 2 keep - 1 suffices (4096 instead of 8192 for 5760-wide frames)."""
     keep = int(keep)
+    if n in DIRECT_LINE_LENGTHS and USE_DIRECT_LINES:
+        # the line length itself factors into 2, 3 and 5: transformed directly (xcg_line_fft's direct
+        # codes), tw_m = exp(-2 pi i k / n); chirp / bspec are unused
+        key = (str(device), n, 0, 0)
+        if key not in _LINES:
+            tw = get_twiddles(n, device)
+            _LINES[key] = (XcLine(tw_m=tw.data_ptr(), chirp=tw.data_ptr(), bspec=tw.data_ptr(), M=n, keep=0), (tw,))
+        return _LINES[key]
     if keep > 0 and bluestein_size_for(n + 2 * keep - 1) >= bluestein_size(n):
         keep = 0  # nothing to gain: same circular length as the classic plan
     key = (str(device), n, direction, keep)
