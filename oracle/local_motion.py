@@ -14,11 +14,13 @@ per batch of patches (estimate_motion_optimizer.py:361-417):
 
 followed by one optimiser step.  This file follows that with torch autograd on the CPU.
 
-Deliberate differences, both stated where they matter:
-  * the reference draws the patches of a pass in random order (patch_utils.py:160-163);
-    batches here are taken in lattice order.  Order only matters through which patches
-    share the last, smaller batch (each batch is a *mean* over its own elements) and
-    through float summation order.
+Patch order: the reference draws the patches of every pass with ``random.shuffle`` on Python's
+global ``random`` state (patch_utils.py:160-164; one call per pass, one per LBFGS closure
+evaluation).  The same call is made here, so for the same ``random.seed`` the batches -- and with
+``lbfgs_patch_subsample`` the patches that are used at all -- are the reference's
+(tests/golden/reference_local_helpers.npz holds the reference's own order for a seed).
+
+Deliberate difference, stated where it matters:
   * the parameters of the un-vendored spline package start at zero (its documented
     default); the third-party semantics of circle / b_envelope / bandpass / fourier
     shift / spline evaluation are the ones in oracle/thirdparty_semantics.py --
@@ -26,6 +28,8 @@ Deliberate differences, both stated where they matter:
 """
 
 from __future__ import annotations
+
+import random
 
 import torch
 
@@ -162,7 +166,7 @@ def estimate_local_motion(image, pixel_spacing, patch_shape, deformation_field_r
                           frequency_range=(300, 10), optimizer_type="adam", grid_type="catmull_rom",
                           loss_type="mse", optimizer_kwargs=None, return_trajectory=False,
                           trajectory_kwargs=None):
-    """estimate_motion_optimizer.py:28-439, lattice-order batches (see the module header)."""
+    """estimate_motion_optimizer.py:28-439, the reference's shuffled batches (module header)."""
     if grid_type not in ("catmull_rom", "bspline"):
         raise ValueError(f"Invalid grid type: {grid_type}. Must be 'catmull_rom' or 'bspline'.")
     prob = LocalMotionProblem(image, pixel_spacing, patch_shape, b_factor, frequency_range)
@@ -187,8 +191,10 @@ def estimate_local_motion(image, pixel_spacing, patch_shape, deformation_field_r
             def closure():
                 opt.zero_grad()
                 tot, n = None, 0
-                for b in range(prob.npatch):  # :287-324, batch_size=1
-                    if sub is not None and b >= sub:
+                order = list(range(prob.npatch))
+                random.shuffle(order)  # get_iterator(batch_size=1, randomized=True), :295-297
+                for pos, b in enumerate(order):  # :287-324, batch_size=1
+                    if sub is not None and pos >= sub:
                         break
                     l = prob.batch_loss(new, init, grid_type, [b], loss_type)
                     tot = l if tot is None else tot + l
@@ -201,8 +207,10 @@ def estimate_local_motion(image, pixel_spacing, patch_shape, deformation_field_r
             avg = float(opt.step(closure).detach())
         else:
             total, n = 0.0, 0
+            order = list(range(prob.npatch))
+            random.shuffle(order)  # get_iterator(batch_size=8), randomized by default (:362)
             for a in range(0, prob.npatch, 8):  # :361 batch_size=8
-                idx = list(range(a, min(a + 8, prob.npatch)))
+                idx = order[a : a + 8]
                 l = prob.batch_loss(new, init, grid_type, idx, loss_type)
                 l.backward()
                 total += l.item()

@@ -443,6 +443,14 @@ def reference_local_motion_vectors():
     out["ipi_patches"] = torch.cat(patches, 0).numpy()  # (npatch, t, ph, pw)
     out["ipi_centers"] = torch.cat(centers, 1).numpy()  # (t, npatch, 3) normalised
     out["ipi_batch_sizes"] = np.asarray([p.shape[0] for p in patches])
+    # the reference's shuffled patch order (random.shuffle on the global state, patch_utils.py:163-164):
+    # two consecutive passes after random.seed(2024), as normalised centres of frame 0
+    import random
+
+    random.seed(2024)
+    for k in range(2):
+        cs = [cb for _, cb in it.get_iterator(batch_size=8, randomized=True)]
+        out[f"ipi_shuffled_centers_{k}"] = torch.cat(cs, 1)[0].numpy()  # (npatch, 3)
     tr = ost.OptimizationTracker(sample_every_n_steps=3, total_steps=8)
     for step in range(8):
         if tr.sample_this_step(step):

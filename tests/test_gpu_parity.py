@@ -1017,14 +1017,41 @@ def test_local_motion_short_runs_follow_the_oracle(mc, dev, optimizer_type, loss
     init = torch.randn(2, 5, 1, 1, generator=torch.Generator().manual_seed(2)) * 0.5
     kw = dict(patch_shape=(32, 32), deformation_field_resolution=(5, 2, 2), initial_deformation_field=init,
               n_iterations=n_it, optimizer_type=optimizer_type, loss_type=loss_type, return_trajectory=True)
+    import random
+
+    # 25 patches in batches of 8: which patch is alone in the last batch of a pass is decided by the
+    # reference's random.shuffle (patch_utils.py:163-164); same seed, same passes
+    random.seed(7)
     ref, rtr = oracle.estimate_local_motion(st, 1.0, **kw)
+    after_oracle = random.random()
+    random.seed(7)
     got, gtr = mc.estimate_local_motion(st.to(dev), 1.0, **kw)
+    assert random.random() == after_oracle  # the global random state advanced identically
     assert got.shape == ref.shape == (2, 5, 2, 2) and got.device.type == "cuda"
     step = float((ref - (oracle.resample_deformation_field(init, (5, 2, 2)) - 0)).abs().max())
     assert float((got.cpu() - ref).abs().max()) <= 0.05 * max(step, 1e-3)
     assert [c.step for c in gtr.checkpoints] == [c.step for c in rtr.checkpoints]
     for a, b in zip(gtr.checkpoints, rtr.checkpoints):
         assert abs(a.loss - b.loss) <= 1e-3 * abs(b.loss) + 1e-9
+
+
+def test_local_motion_lbfgs_subsample_uses_the_shuffled_patches(mc, dev):
+    """lbfgs_patch_subsample keeps the FIRST n patches of every closure evaluation's shuffled order
+    (estimate_motion_optimizer.py:295-303): a random subset per evaluation, the reference's for the seed."""
+    import random
+
+    st = _local_case(t=4, h=96, w=96, seed=3)
+    kw = dict(patch_shape=(32, 32), deformation_field_resolution=(4, 2, 2), n_iterations=2,
+              optimizer_type="lbfgs", loss_type="mse", optimizer_kwargs={"lbfgs_patch_subsample": 6})
+    random.seed(11)
+    ref = oracle.estimate_local_motion(st, 1.0, **kw)
+    random.seed(11)
+    got = mc.estimate_local_motion(st.to(dev), 1.0, **kw)
+    scale = max(float(ref.abs().max()), 1e-3)
+    assert float((got.cpu() - ref).abs().max()) <= 0.05 * scale
+    random.seed(12)  # another seed, other subsets: a different (but again matching) answer
+    other = mc.estimate_local_motion(st.to(dev), 1.0, **kw)
+    assert float((other - got).abs().max()) > 0
 
 
 def test_local_motion_recovers_a_known_drift(mc, dev):

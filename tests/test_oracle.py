@@ -481,6 +481,16 @@ def test_oracle_patches_and_centres_match_the_reference_iterator(refl):
     assert torch.equal(patches, torch.from_numpy(refl["ipi_patches"]))
     n = patches.shape[0]
     assert list(refl["ipi_batch_sizes"]) == [min(4, n - a) for a in range(0, n, 4)]
+    # the shuffled order of two consecutive passes after random.seed(2024): one random.shuffle of
+    # range(npatch) per pass reproduces the reference's (patch_utils.py:161-166)
+    import random
+
+    random.seed(2024)
+    lattice_order = torch.from_numpy(refl["ipi_centers"])[0]
+    for k in range(2):
+        order = list(range(n))
+        random.shuffle(order)
+        assert torch.equal(lattice_order[order], torch.from_numpy(refl[f"ipi_shuffled_centers_{k}"])), k
 
 
 def test_trackers_match_the_reference(refl):

@@ -9,15 +9,18 @@ gradient replaces autograd; the optimisers are torch.optim's own, fed through a
 torch.autograd.Function, so 'adam', 'sgd', 'rmsprop' and 'lbfgs' behave as in the reference
 (same defaults, estimate_motion_optimizer.py:517-608).
 
-Patch order: the reference shuffles the patches of every pass (patch_utils.py:160-163);
-here batches are taken in lattice order, which is the same loss whenever the number of
-patches is a multiple of the batch size (8) and otherwise differs only in which patches
-share the last, smaller batch.
+Patch order: the reference shuffles the patches of every pass with ``random.shuffle`` on Python's
+global ``random`` state (patch_utils.py:160-164: once per pass, once per LBFGS closure evaluation).
+The order only enters through which patches share the last, smaller batch of a pass (a batch's loss
+is the mean over its own patches) and, with ``lbfgs_patch_subsample``, through which patches are
+used at all.  The same ``random.shuffle`` call is made here, so for the same ``random.seed`` the
+per-patch weights are the reference's and the global random state advances as it does there.
 """
 
 from __future__ import annotations
 
 import math
+import random
 
 import numpy as np
 import torch
@@ -196,28 +199,46 @@ def estimate_local_motion(img: torch.Tensor, pixel_spacing, patch_shape, deforma
     opt = setup_optimizer(optimizer_type, [new], **okw)
     lbfgs = optimizer_type.lower() == "lbfgs"
     npatch = prob.npatch
-    if lbfgs:  # closure: batches of one patch, averaged (:287-336); optional subsample of the first patches
+    # Per-patch weights of one pass.  The reference shuffles the patch list (random.shuffle, once
+    # per pass / closure evaluation) and cuts it into batches: a patch's weight is 1 / (size of the
+    # batch its POSITION in the shuffled list falls into); under LBFGS the first `used` positions
+    # are single-patch batches averaged, the rest is skipped.
+    if lbfgs:  # closure: batches of one patch, averaged (:287-336)
         sub = okw.get("lbfgs_patch_subsample", None)
         used = npatch if sub is None else max(0, min(int(sub), npatch))
-        wb = torch.zeros(npatch, dtype=torch.float64, device=dev)
+        by_pos = np.zeros(npatch, dtype=np.float64)
         if used:
-            wb[:used] = 1.0 / used
+            by_pos[:used] = 1.0 / used
         nbatch = 1
     else:  # batches of 8, each a mean over its own patches, gradients accumulated (:361-417)
         sizes = np.minimum(BATCH, npatch - (np.arange(npatch) // BATCH) * BATCH)
-        wb = torch.from_numpy(1.0 / sizes.astype(np.float64)).to(dev)
+        by_pos = 1.0 / sizes.astype(np.float64)
         nbatch = (npatch + BATCH - 1) // BATCH
+    uniform = bool(np.all(by_pos == by_pos[0]))
+    wb_const = torch.from_numpy(by_pos).to(dev)
+
+    def pass_weights():
+        order = list(range(npatch))
+        random.shuffle(order)  # always: the global random state must advance as in the reference
+        if uniform:
+            return wb_const
+        w = np.empty(npatch, dtype=np.float64)
+        w[np.asarray(order, dtype=np.int64)] = by_pos
+        return torch.from_numpy(w).to(dev)
+
     for it in range(int(n_iterations)):
         if lbfgs:
             def closure():
                 opt.zero_grad()
-                if not bool(wb.any()):
+                wb = pass_weights()
+                if not used:
                     return torch.tensor(0.0, device=dev, requires_grad=True)
                 loss = _Loss.apply(prob.shifts_px(new, init_data), prob, wb, loss_type)
                 loss.backward()
                 return loss
             avg = opt.step(closure)
         else:
+            wb = pass_weights()
             loss = _Loss.apply(prob.shifts_px(new, init_data), prob, wb, loss_type)
             loss.backward()
             opt.step()
