@@ -46,8 +46,11 @@ class MoviePipeline:
         # the estimator's stream gets the higher priority: its short, latency-bound kernels then
         # slot in between the waves of the long HBM-bound warp instead of queueing behind them
         # (measured: 19.4-19.7 k -> 20.1-20.4 k frames/s on 40 x 4096^2 stacks)
-        self._s_est = torch.cuda.Stream(self.device, priority=-1) if overlap else None
-        self._s_warp = torch.cuda.Stream(self.device, priority=0) if overlap else None
+        import os
+
+        pe, pw = (int(x) for x in os.environ.get("MC_PIPE_PRIORITIES", "-1,0").split(","))
+        self._s_est = torch.cuda.Stream(self.device, priority=pe) if overlap else None
+        self._s_warp = torch.cuda.Stream(self.device, priority=pw) if overlap else None
 
     # the two stages, each enqueued on whatever stream is current
     def _estimate(self, img: torch.Tensor) -> torch.Tensor:
