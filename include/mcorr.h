@@ -309,6 +309,32 @@ int mc_pixel_shifts(const float* lattice, int GH, int GW, int h, int w, float pi
 int mc_pixel_shifts_at(const float* lattice, int GH, int GW, int h, int w, float pixel_spacing,
                        const float* coords_yx, int64_t n, float* out, void* stream);
 
+/* ---- full-spectrum transforms with a row-major spectrum (power-of-two sizes) ---------------
+ * What correct_motion_fast (correct_motion.py:484-496) and the exposure-filtered sum
+ * (examples/ttMotion.py:331-351) run on when H and W are powers of two (256 <= H <= 4096,
+ * 64 <= W <= 8192; MC_ERR_UNSUPPORTED otherwise: use the pruned-engine entry points below).
+ * S[job][y][pitch] complex, pitch = mc_full_spectrum_pitch(W) = W/2 + 1 rounded up to 16.
+ *   mc_full_rows_forward   rfft along x of njobs frames (origin src + job_off[j], rows row_stride
+ *                          floats apart) -> S
+ *   mc_full_cols_shift     per job: fft along y, * exp(-2 pi i (fy sy + fx sx)) * scale,
+ *                          shifts[j] = (sy, sx) px, ifft along y, in place
+ *   mc_full_cols_dose      A += sum_f q_f(k) fft_y(S_f) over the nframes frames of S (frames frame0..
+ *                          of total_frames; first: A starts at zero); last: A *= scale / sqrt(sum_f
+ *                          q_f^2) over ALL frames and is transformed back along y (then
+ *                          mc_full_rows_inverse(A) is the exposure-filtered sum).  q_f as in
+ *                          mc_dose_accumulate.  A: H * pitch complex.
+ *   mc_full_rows_inverse   irfft along x (c2r, unscaled) of S -> real rows at out + out_off[j] */
+int mc_full_spectrum_pitch(int W);
+int mc_full_rows_forward(const float* src, const int64_t* job_off, int64_t row_stride, void* S,
+                         const void* tw_row, int njobs, int H, int W, int pitch, void* stream);
+int mc_full_cols_shift(void* S, const float* shifts, const void* tw_col, float scale, int njobs, int H, int W,
+                       int pitch, void* stream);
+int mc_full_cols_dose(const void* S, int nframes, int frame0, int total_frames, void* A, const void* tw_col,
+                      int H, int W, int pitch, float pixel_size, float pre_exposure, float dose_per_frame,
+                      float voltage, int first, int last, float scale, void* stream);
+int mc_full_rows_inverse(const void* S, float* out, const int64_t* out_off, int64_t out_stride,
+                         const void* tw_row, int njobs, int H, int W, int pitch, void* stream);
+
 /* correct_motion_fast (correct_motion.py:430-498): K3 variant multiplying spectrum
  * idx[p] by exp(-2*pi*i*(fy*sy+fx*sx)), shifts[p]=(sy,sx) px, then inverse columns. */
 int mc_fourier_shift_cols_inverse(const void* S, const int* idx, const float* shifts, void* T2,

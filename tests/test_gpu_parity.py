@@ -1621,3 +1621,60 @@ def test_evaluate_deformation_field_on_scattered_points(mc, dev):
             ref = oracle.evaluate_deformation_field(field, tyx, gt)
             assert got.shape == (7, 11, shape[0])
             assert float((got - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+# ------------------------------------------------------------------ row-major full-spectrum kernels (full_fft.hip)
+
+
+@pytest.mark.parametrize("shape", [(3, 256, 64), (2, 256, 256), (2, 512, 1024), (3, 1024, 512), (2, 2048, 256),
+                                   (2, 4096, 128), (1, 256, 8192), (2, 4096, 4096)])
+def test_row_major_fourier_shift(mc, dev, shape):
+    """correct_motion_fast on power-of-two frames (rows forward, one in-place column kernel for
+    forward + phase ramp + inverse, rows inverse; spectrum row-major) against the oracle, against
+    the pruned engine's transposed layout, and -- for integer shifts -- against an exact roll."""
+    from torch_motion_correction_amd import engine
+
+    t, h, w = shape
+    g = torch.Generator().manual_seed(h + w)
+    img = torch.randn(t, h, w, generator=g)
+    sh = torch.randn(2, t, 1, 1, generator=g) * 3
+    got = mc.correct_motion_fast(img.to(dev), sh.clone().to(dev)).cpu()
+    if h * w <= 1024 * 1024:
+        assert rel_err(got, oracle.correct_motion_fast(img, sh.clone())) <= 2e-5
+    try:
+        engine.FULL_ROW_MAJOR = False
+        old = mc.correct_motion_fast(img.to(dev), sh.clone().to(dev)).cpu()
+    finally:
+        engine.FULL_ROW_MAJOR = True
+    assert rel_err(got, old) <= 2e-5
+    ish = torch.tensor([[3.0, -7.0]] * t).t()[:, :, None, None].contiguous()  # field +3 / -7 -> shift by (-3, +7)
+    rolled = mc.correct_motion_fast(img.to(dev), ish.clone().to(dev)).cpu()
+    assert rel_err(rolled, torch.roll(img, shifts=(-3, 7), dims=(1, 2))) <= 1e-5
+
+
+@pytest.mark.parametrize("shape,ps,dose,pre,kv", [((6, 256, 256), 1.0, 1.5, 0.0, 300.0),
+                                                  ((5, 512, 256), 1.3, 0.8, 2.0, 200.0),
+                                                  ((3, 256, 1024), 0.83, 2.5, 0.5, 100.0)])
+def test_row_major_dose_weighted_sum(mc, dev, shape, ps, dose, pre, kv):
+    """The exposure-filtered sum with the weighted accumulation inside the forward column pass
+    (frame loop in registers, chunks of frames carried through A) against the oracle and against
+    the separate accumulate kernel on the transposed layout."""
+    from torch_motion_correction_amd import engine
+
+    g = torch.Generator().manual_seed(sum(shape))
+    m = torch.randn(*shape, generator=g) * 2.0 + 5.0
+    got = mc.dose_weighted_sum(m.to(dev), ps, dose, pre_exposure=pre, voltage=kv).cpu()
+    ref = oracle.dose_weighted_sum(m, ps, dose, pre_exposure=pre, voltage=kv)
+    assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    try:  # two frames per chunk: the accumulator goes through A between chunks
+        ws, engine.WORKSPACE_BYTES = engine.WORKSPACE_BYTES, 2 * shape[1] * (shape[2] // 2 + 16) * 8
+        chunked = mc.dose_weighted_sum(m.to(dev), ps, dose, pre_exposure=pre, voltage=kv).cpu()
+    finally:
+        engine.WORKSPACE_BYTES = ws
+    assert float((chunked - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    try:
+        engine.FULL_ROW_MAJOR = False
+        old = mc.dose_weighted_sum(m.to(dev), ps, dose, pre_exposure=pre, voltage=kv).cpu()
+    finally:
+        engine.FULL_ROW_MAJOR = True
+    assert float((got - old).abs().max()) <= 2e-5 * float(ref.abs().max())

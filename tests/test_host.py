@@ -112,15 +112,25 @@ def test_unsupported_sizes_fail_loudly():
 
 
 def test_super_resolution_frames_fit_the_band_limited_transforms():
-    """8184 x 11520 (BASELINE config 5 frames): the band-limited estimate runs on chirp-z lines of
-    8192 points (output-pruned forward rows) and 16384 points (columns, inverse rows)."""
+    """8184 x 11520 (BASELINE config 5 frames): the rows (5760 = 2^7 3^2 5 complex points) are
+    transformed directly by the mixed-radix passes (round 2; chirp-z lines of 8192 / 16384 points
+    before), the columns (8184 = 2^3 3 11 31) run on chirp-z lines of 16384 points."""
     low, high = plan.band_limits((300, 10), 1.0)
     g = plan.xc_geometry(8184, 11520, high, 8184 / 4, 8184 / 8)
     assert (g.nkx, g.kyp + g.kyn) == (1153, 1637) and g.RG >= 1 and 8184 % g.RG == 0
     fwd, _ = plan.line_plan(5760, -1, "cpu", keep=g.nkx + 1)
     inv, _ = plan.line_plan(5760, +1, "cpu")
     col, _ = plan.line_plan(8184, -1, "cpu")
-    assert (fwd.M, fwd.keep, inv.M, col.M) == (8192, g.nkx + 1, 16384, 16384)
+    assert (fwd.M, fwd.keep, inv.M, col.M) == (5760, 0, 5760, 16384)
+    try:  # the chirp-z plans are still there (other widths, and as the cross-check of the direct lines)
+        plan.USE_DIRECT_LINES = False
+        plan._LINES.clear()
+        fwd, _ = plan.line_plan(5760, -1, "cpu", keep=g.nkx + 1)
+        inv, _ = plan.line_plan(5760, +1, "cpu")
+        assert (fwd.M, fwd.keep, inv.M) == (8192, g.nkx + 1, 16384)
+    finally:
+        plan.USE_DIRECT_LINES = True
+        plan._LINES.clear()
     assert 8 * (plan.bluestein_size(5760) * 17 // 16 + 1 + g.nkx * (g.RG + 1)) <= 160 * 1024
 
 

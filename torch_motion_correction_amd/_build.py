@@ -16,7 +16,8 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 LIB_PATH = os.path.join(PKG_DIR, "libmcorr.so")
-SOURCES = ["plan_stats.hip", "xc_fft.hip", "field_post.hip", "warp.hip", "local_motion.hip", "polyphase.hip"]
+SOURCES = ["xc_fft.hip", "plan_stats.hip", "field_post.hip", "warp.hip", "local_motion.hip", "polyphase.hip",
+           "full_fft.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 # warp.hip: the SLP vectoriser turns the per-pixel coordinate chain into v_pk_* instructions fed by

@@ -72,6 +72,11 @@ SIGNATURES = {
     "mc_warp_rigid_phase": [vp, i32, i32, i32, vp, vp, vp, vp, i32, vp],
     "mc_pixel_shifts": [vp, i32, i32, i32, i32, f32, vp, vp, vp],
     "mc_pixel_shifts_at": [vp, i32, i32, i32, i32, f32, vp, i64, vp, vp],
+    "mc_full_spectrum_pitch": [i32],
+    "mc_full_rows_forward": [vp, vp, i64, vp, vp, i32, i32, i32, i32, vp],
+    "mc_full_cols_shift": [vp, vp, vp, f32, i32, i32, i32, i32, vp],
+    "mc_full_cols_dose": [vp, i32, i32, i32, vp, vp, i32, i32, i32, f32, f32, f32, f32, i32, i32, f32, vp],
+    "mc_full_rows_inverse": [vp, vp, vp, i64, vp, i32, i32, i32, i32, vp],
     "mc_fourier_shift_cols_inverse": [vp, vp, vp, vp, vp, f32, i32, GP, vp],
     "mc_xc_rows_inverse_store": [vp, vp, vp, i64, vp, i32, GP, vp],
     "mc_xcg_rows_forward": [vp, vp, i64, vp, vp, vp, vp, vp, LP, i32, GP, vp],

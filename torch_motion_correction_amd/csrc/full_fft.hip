@@ -1,0 +1,497 @@
+// Full-spectrum 2-D real transforms with a ROW-MAJOR spectrum, power-of-two sizes: what
+// correct_motion_fast (correct_motion.py:484-496: rfftn -> fourier_shift_dft_2d -> irfftn) and the
+// exposure-filtered frame sum (examples/ttMotion.py:331-351: rfft2 -> dose_weight_movie -> irfft2 ->
+// sum) run on.
+//
+// The pruned engine of xc_fft.hip hands its row pass output to the column pass TRANSPOSED
+// (T1[job][kx][y]); with all nkx = W/2 + 1 bins kept that needs an LDS stage of nkx x RG bins per
+// workgroup (147 KB for W = 4096: one workgroup per CU, 1.1 TB/s -- 1.9 ms per 15 frames, two thirds
+// of correct_motion_fast's 12 ms per 40 x 4096^2 stack).  Here the spectrum stays row-major,
+//     S[job][y][pitch]   complex, pitch = nkx rounded up to 16 (whole 128-byte lines per 16 columns),
+// so a row pass reads or writes whole rows and needs no stage, and the COLUMN pass does the strided
+// access instead: a workgroup owns two adjacent columns (16 bytes per row), stages them in two LDS
+// lines, transforms forward, applies the pointwise step and transforms back IN PLACE -- one read and
+// one write of S for what were two kernels and a round trip.  The eight workgroups whose column
+// pairs share 128-byte lines are dispatched next to each other on one XCD (blockIdx mapping below),
+// so every line is fetched from HBM once and written back whole.
+//
+//   full_rows_fwd   rows:  samples -> real FFT(W) -> S[job][y][0..W/2]
+//   full_cols_shift cols:  S column pair -> FFT(H) -> * exp(-2 pi i (fy sy + fx sx)) / (H W) -> IFFT(H) -> S
+//   full_cols_dose  cols:  sum_f q_f(k) FFT_H(S_f column) accumulated in registers over the frames
+//                          of a chunk (+ A) -> A; on the last chunk / sqrt(sum q^2), IFFT(H), / (H W)
+//   full_rows_inv   rows:  S[job][y][0..W/2] -> c2r pack -> IFFT(W/2) -> real rows
+#include "mc_fft.h"
+#include "mcorr.h"
+
+// blockIdx.x -> column pair: the 8 pairs of one 128-byte line group on one XCD, consecutively
+__device__ __forceinline__ int full_pair_of_block(int b, int npairs) {
+  const int ngroups = (npairs + 7) / 8;
+  if (ngroups < 8) return b;  // tiny widths: no mapping
+  const int xcd = b & 7, i = b >> 3;
+  const int grp = i >> 3, within = i & 7;
+  const int G = grp * 8 + xcd;
+  // groups beyond the last multiple of 8 keep the plain order
+  const int full = (ngroups / 8) * 8;
+  if (b >= full * 8) return b;
+  return G * 8 + within;
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(MC_WG) void full_rows_fwd(const float* __restrict__ src,
+                                                       const int64_t* __restrict__ job_off,
+                                                       int64_t row_stride, cfloat* __restrict__ S, int H,
+                                                       int pitch, const cfloat* __restrict__ tw_row,
+                                                       int rows_per_wg) {
+  constexpr int N = 1 << LOGN;  // complex points = W / 2
+  __shared__ __attribute__((aligned(16))) cfloat line[lds_len(N)];
+  const int tid = threadIdx.x;
+  const int job = blockIdx.y;
+  const float* base = src + job_off[job];
+  for (int r = 0; r < rows_per_wg; ++r) {
+    const int y = blockIdx.x * rows_per_wg + r;
+    if (y >= H) break;  // workgroup-uniform
+    const float* row = base + (int64_t)y * row_stride;
+    auto load = [&](int j) {
+      const float2 v = *reinterpret_cast<const float2*>(row + 2 * j);
+      return cmake(v.x, v.y);
+    };
+    auto keep = [&](int k, cfloat v) { line[lpad(k)] = v; };
+    wg_fft<N, -1>(line, tid, tw_row, 2, load, keep);
+    __syncthreads();
+    // real-FFT unpack: X[k] = (Z[k] + conj(Z[N-k]))/2 - i/2 * w^k * (Z[k] - conj(Z[N-k])), k = 0..N
+    cfloat* out = S + ((int64_t)job * H + y) * pitch;
+    for (int k = tid; k <= N; k += MC_WG) {
+      const cfloat zk = line[lpad(k & (N - 1))];
+      const cfloat zm = cconj(line[lpad((N - k) & (N - 1))]);
+      const cfloat sm = cadd(zk, zm), d = csub(zk, zm);
+      const cfloat w = (k < N) ? tw_row[k] : cmake(-1.f, 0.f);
+      const cfloat wd = cmul(w, d);  // -i*wd = (wd.y, -wd.x)
+      out[k] = cmake(0.5f * (sm.x + wd.y), 0.5f * (sm.y - wd.x));
+    }
+    __syncthreads();  // the next row's first pass writes the line
+  }
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(MC_WG) void full_rows_inv(const cfloat* __restrict__ S, float* __restrict__ out,
+                                                       const int64_t* __restrict__ out_off, int64_t out_stride,
+                                                       int H, int pitch, const cfloat* __restrict__ tw_row,
+                                                       int rows_per_wg) {
+  constexpr int N = 1 << LOGN;
+  __shared__ __attribute__((aligned(16))) cfloat line[lds_len(N)];
+  __shared__ __attribute__((aligned(16))) cfloat xs[N + 16];
+  const int tid = threadIdx.x;
+  const int job = blockIdx.y;
+  for (int r = 0; r < rows_per_wg; ++r) {
+    const int y = blockIdx.x * rows_per_wg + r;
+    if (y >= H) break;
+    const cfloat* in = S + ((int64_t)job * H + y) * pitch;
+    for (int k = tid; k <= N; k += MC_WG) xs[k] = in[k];
+    __syncthreads();
+    // c2r pack: Z[k] = (X[k] + conj(X[N-k])) + i * conj(w^k) * (X[k] - conj(X[N-k]))
+    auto load = [&](int k) {
+      cfloat xk = xs[k];
+      cfloat xm = cconj(xs[N - k]);
+      if (k == 0) {  // c2r ignores the imaginary part of the DC and Nyquist bins (pocketfft)
+        xk.y = 0.f;
+        xm.y = 0.f;
+      }
+      const cfloat sm = cadd(xk, xm), d = csub(xk, xm);
+      cfloat w = tw_row[k];
+      w.y = -w.y;
+      const cfloat wd = cmul(w, d);  // i*wd = (-wd.y, wd.x)
+      return cmake(sm.x - wd.y, sm.y + wd.x);
+    };
+    float* orow = out + out_off[job] + (int64_t)y * out_stride;
+    auto store = [&](int n, cfloat v) { *reinterpret_cast<float2*>(orow + 2 * n) = make_float2(v.x, v.y); };
+    wg_fft<N, +1>(line, tid, tw_row, 2, load, store);
+    __syncthreads();  // xs and the line are rewritten by the next row
+  }
+}
+
+// signed frequency of row ky of an H-point transform (torch.fft.fftfreq)
+__device__ __forceinline__ float full_fy(int ky, int H) {
+  const int kk = (ky < (H + 1) / 2) ? ky : ky - H;
+  return (float)kk * (float)(1.0 / (double)H);
+}
+
+template <int LOGH>
+__global__ __launch_bounds__(MC_WG) void full_cols_shift(cfloat* __restrict__ S, int W, int pitch,
+                                                         const cfloat* __restrict__ tw_col,
+                                                         const float* __restrict__ shifts, float scale) {
+  constexpr int H = 1 << LOGH;
+  extern __shared__ __attribute__((aligned(16))) char smem_fc[];
+  cfloat* lines[2] = {reinterpret_cast<cfloat*>(smem_fc), reinterpret_cast<cfloat*>(smem_fc) + lds_len(H)};
+  const int tid = threadIdx.x;
+  const int npairs = pitch / 2;
+  const int kx0 = 2 * full_pair_of_block(blockIdx.x, npairs);
+  const int job = blockIdx.y;
+  cfloat* base = S + (int64_t)job * H * pitch + kx0;
+  for (int i = tid; i < H; i += MC_WG) {
+    const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)i * pitch);
+    lines[0][lpad(i)] = cmake(v.x, v.y);
+    lines[1][lpad(i)] = cmake(v.z, v.w);
+  }
+  __syncthreads();
+  const float sy = shifts[2 * job], sx = shifts[2 * job + 1];
+  const float m2pi = -6.283185307179586f;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    cfloat* line = lines[c];
+    const float fx = (float)(kx0 + c) * (float)(1.0 / (double)W);  // torch.fft.rfftfreq: k * (1/n)
+    auto rd = [&](int i) { return line[lpad(i)]; };
+    auto ramp = [&](int ky, cfloat v) {
+      const float ang = (m2pi * full_fy(ky, H)) * sy + (m2pi * fx) * sx;
+      float sn, cs;
+      sincosf(ang, &sn, &cs);
+      line[lpad(ky)] = cscale(cmul(v, cmake(cs, sn)), scale);
+    };
+    wg_fft_inplace<H, -1>(line, tid, tw_col, 1, rd, ramp);
+    __syncthreads();
+    auto back = [&](int y, cfloat v) { line[lpad(y)] = v; };
+    wg_fft_inplace<H, +1>(line, tid, tw_col, 1, rd, back);
+    __syncthreads();
+  }
+  for (int i = tid; i < H; i += MC_WG) {
+    const cfloat a = lines[0][lpad(i)], b = lines[1][lpad(i)];
+    *reinterpret_cast<float4*>(base + (int64_t)i * pitch) = make_float4(a.x, a.y, b.x, b.y);
+  }
+}
+
+// Exposure filter of examples/ttMotion.py:331-351 (crit_exposure_bfactor = -1), as dose_accumulate_kernel
+// (plan_stats.hip) defines it: q_f(k) = exp(-0.5 N_f / N_c(|k|)), N_c = (0.24499 |k|^-1.6649 + 2.8141)
+// vscale, N_f = pre + dose_per_frame (f + 1), |k| in 1/Angstrom clamped at 1e-6.
+__device__ __forceinline__ float full_dose_mh(int kx, int ky, int W, int H, float pixel_size, float vscale) {
+  const float fy = full_fy(ky, H);
+  const float fx = (float)kx * (float)(1.0 / (double)W);
+  const float f = fmaxf(sqrtf(fy * fy + fx * fx) / pixel_size, 1e-6f);
+  const float ncrit = (0.24499f * powf(f, -1.6649f) + 2.8141f) * vscale;
+  return -0.5f / ncrit;
+}
+
+template <int LOGH>
+__global__ __launch_bounds__(MC_WG) void full_cols_dose(const cfloat* __restrict__ S, int nframes, int frame0,
+                                                        int total_frames, cfloat* __restrict__ A, int W,
+                                                        int pitch, const cfloat* __restrict__ tw_col,
+                                                        float pixel_size, float pre_exposure,
+                                                        float dose_per_frame, float vscale, int first, int last,
+                                                        float scale) {
+  constexpr int H = 1 << LOGH;
+  // outputs the last pass hands to one thread: H / 256 for H >= 1024; for 512 / 256 points the last
+  // pass (radix 8 / 4) runs on 64 threads that get 8 / 4 outputs each
+  constexpr int SLOTS = (H / MC_WG) > 8 ? (H / MC_WG) : 8;
+  extern __shared__ __attribute__((aligned(16))) char smem_fc[];
+  cfloat* lines[2] = {reinterpret_cast<cfloat*>(smem_fc), reinterpret_cast<cfloat*>(smem_fc) + lds_len(H)};
+  const int tid = threadIdx.x;
+  const int npairs = pitch / 2;
+  const int kx0 = 2 * full_pair_of_block(blockIdx.x, npairs);
+  cfloat acc[2][SLOTS];
+  float mh[2][SLOTS];
+  int kys[SLOTS];
+  int nslots = 0;
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) kys[s] = 0;
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      acc[c][s] = cmake(0.f, 0.f);
+      mh[c][s] = 0.f;
+    }
+  for (int j = 0; j < nframes; ++j) {
+    const cfloat* base = S + (int64_t)j * H * pitch + kx0;
+    for (int i = tid; i < H; i += MC_WG) {
+      const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)i * pitch);
+      lines[0][lpad(i)] = cmake(v.x, v.y);
+      lines[1][lpad(i)] = cmake(v.z, v.w);
+    }
+    __syncthreads();
+    const float dose = pre_exposure + dose_per_frame * (float)(frame0 + j + 1);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      cfloat* line = lines[c];
+      auto rd = [&](int i) { return line[lpad(i)]; };
+      int slot = 0;  // the last pass calls `take` SLOTS times per thread, in a fixed (unrolled) order
+      auto take = [&](int ky, cfloat v) {
+        if (j == 0) {
+          kys[slot] = ky;
+          mh[c][slot] = full_dose_mh(kx0 + c, ky, W, H, pixel_size, vscale);
+        }
+        const float q = expf(mh[c][slot] * dose);
+        acc[c][slot].x += q * v.x;
+        acc[c][slot].y += q * v.y;
+        ++slot;
+      };
+      wg_fft_inplace<H, -1>(line, tid, tw_col, 1, rd, take);
+      nslots = slot;
+    }
+    __syncthreads();  // the next frame overwrites the lines
+  }
+  // accumulator column pair: add what earlier chunks left in A, on the last chunk "restore the power"
+  // (/ sqrt(sum_f q_f^2) over ALL frames), transform back and scale
+  cfloat* abase = A + kx0;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      if (s >= nslots) continue;
+      cfloat a = acc[c][s];
+      const int ky = kys[s];
+      if (!first) {
+        const cfloat prev = abase[(int64_t)ky * pitch + c];
+        a.x += prev.x;
+        a.y += prev.y;
+      }
+      if (last) {
+        float qq = 0.f;
+        for (int f = 0; f < total_frames; ++f) {
+          const float q = expf(mh[c][s] * (pre_exposure + dose_per_frame * (float)(f + 1)));
+          qq += q * q;
+        }
+        const float r = scale / sqrtf(qq);
+        a.x *= r;
+        a.y *= r;
+      }
+      lines[c][lpad(ky)] = a;
+    }
+  }
+  __syncthreads();
+  if (last) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      cfloat* line = lines[c];
+      auto rd = [&](int i) { return line[lpad(i)]; };
+      auto back = [&](int y, cfloat v) { line[lpad(y)] = v; };
+      wg_fft_inplace<H, +1>(line, tid, tw_col, 1, rd, back);
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < H; i += MC_WG) {
+    const cfloat a = lines[0][lpad(i)], b = lines[1][lpad(i)];
+    *reinterpret_cast<float4*>(abase + (int64_t)i * pitch) = make_float4(a.x, a.y, b.x, b.y);
+  }
+}
+
+// ---- H = 4096: the register-resident radix-16 transform (mc_fft.h: 16 x 16 x 16, three passes,
+// two exchanges through ONE 32 KiB line, 4 barriers).  Thread tid owns inputs 256 n1 + tid and
+// outputs tid + 256 k3 -- the same rows -- so a column pair goes global -> registers -> forward ->
+// pointwise -> inverse -> global without ever being staged: 32 KiB of LDS per workgroup instead of
+// 70 (3-4 workgroups per CU instead of 2) and a third of the barriers.
+__global__ __launch_bounds__(MC_WG) void full_cols_shift_r16(cfloat* __restrict__ S, int W, int pitch,
+                                                             const cfloat* __restrict__ tw_col,
+                                                             const float* __restrict__ shifts, float scale) {
+  constexpr int H = 4096;
+  __shared__ __attribute__((aligned(16))) cfloat line[H];
+  const int tid = threadIdx.x;
+  const int kx0 = 2 * full_pair_of_block(blockIdx.x, pitch / 2);
+  const int job = blockIdx.y;
+  cfloat* base = S + (int64_t)job * H * pitch + kx0;
+  cfloat v[2][16];
+#pragma unroll
+  for (int n1 = 0; n1 < 16; ++n1) {
+    const float4 q = *reinterpret_cast<const float4*>(base + (int64_t)(256 * n1 + tid) * pitch);
+    v[0][n1] = cmake(q.x, q.y);
+    v[1][n1] = cmake(q.z, q.w);
+  }
+  const float sy = shifts[2 * job], sx = shifts[2 * job + 1];
+  const float m2pi = -6.283185307179586f;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const float fx = (float)(kx0 + c) * (float)(1.0 / (double)W);
+    auto in = [&](int n1, int) { return v[c][n1]; };
+    auto ramp = [&](int k, cfloat x) {
+      const float ang = (m2pi * full_fy(k, H)) * sy + (m2pi * fx) * sx;
+      float sn, cs;
+      sincosf(ang, &sn, &cs);
+      v[c][(k - tid) >> 8] = cscale(cmul(x, cmake(cs, sn)), scale);
+    };
+    wg_fft4096_r16<-1, 8, 8>(line, tid, tw_col, in, ramp);
+    __syncthreads();
+    auto back = [&](int k, cfloat x) { v[c][(k - tid) >> 8] = x; };
+    wg_fft4096_r16<+1, 8, 8>(line, tid, tw_col, in, back);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int n1 = 0; n1 < 16; ++n1)
+    *reinterpret_cast<float4*>(base + (int64_t)(256 * n1 + tid) * pitch) =
+        make_float4(v[0][n1].x, v[0][n1].y, v[1][n1].x, v[1][n1].y);
+}
+
+__global__ __launch_bounds__(MC_WG) void full_cols_dose_r16(const cfloat* __restrict__ S, int nframes, int frame0,
+                                                            int total_frames, cfloat* __restrict__ A, int W,
+                                                            int pitch, const cfloat* __restrict__ tw_col,
+                                                            float pixel_size, float pre_exposure,
+                                                            float dose_per_frame, float vscale, int first, int last,
+                                                            float scale) {
+  constexpr int H = 4096;
+  __shared__ __attribute__((aligned(16))) cfloat line[H];
+  const int tid = threadIdx.x;
+  const int kx0 = 2 * full_pair_of_block(blockIdx.x, pitch / 2);
+  cfloat acc[2][16];
+  float mh[2][16];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int k3 = 0; k3 < 16; ++k3) {
+      acc[c][k3] = cmake(0.f, 0.f);
+      mh[c][k3] = full_dose_mh(kx0 + c, tid + 256 * k3, W, H, pixel_size, vscale);
+    }
+  for (int j = 0; j < nframes; ++j) {
+    const cfloat* base = S + (int64_t)j * H * pitch + kx0;
+    cfloat v[2][16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+      const float4 q = *reinterpret_cast<const float4*>(base + (int64_t)(256 * n1 + tid) * pitch);
+      v[0][n1] = cmake(q.x, q.y);
+      v[1][n1] = cmake(q.z, q.w);
+    }
+    const float dose = pre_exposure + dose_per_frame * (float)(frame0 + j + 1);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      auto in = [&](int n1, int) { return v[c][n1]; };
+      auto take = [&](int k, cfloat x) {
+        const int k3 = (k - tid) >> 8;
+        const float q = expf(mh[c][k3] * dose);
+        acc[c][k3].x += q * x.x;
+        acc[c][k3].y += q * x.y;
+      };
+      wg_fft4096_r16<-1, 8, 8>(line, tid, tw_col, in, take);
+      __syncthreads();
+    }
+  }
+  cfloat* abase = A + kx0;
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int k3 = 0; k3 < 16; ++k3) {
+      cfloat a = acc[c][k3];
+      if (!first) {
+        const cfloat prev = abase[(int64_t)(tid + 256 * k3) * pitch + c];
+        a.x += prev.x;
+        a.y += prev.y;
+      }
+      if (last) {
+        float qq = 0.f;
+        for (int f = 0; f < total_frames; ++f) {
+          const float q = expf(mh[c][k3] * (pre_exposure + dose_per_frame * (float)(f + 1)));
+          qq += q * q;
+        }
+        const float r = scale / sqrtf(qq);
+        a.x *= r;
+        a.y *= r;
+      }
+      acc[c][k3] = a;
+    }
+  if (last) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      auto in = [&](int n1, int) { return acc[c][n1]; };
+      auto back = [&](int k, cfloat x) { acc[c][(k - tid) >> 8] = x; };
+      wg_fft4096_r16<+1, 8, 8>(line, tid, tw_col, in, back);
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int n1 = 0; n1 < 16; ++n1)
+    *reinterpret_cast<float4*>(abase + (int64_t)(256 * n1 + tid) * pitch) =
+        make_float4(acc[0][n1].x, acc[0][n1].y, acc[1][n1].x, acc[1][n1].y);
+}
+
+static bool full_sizes_ok(int H, int W, int pitch) {
+  return mc_is_pow2(H) && mc_is_pow2(W) && H >= 256 && H <= 4096 && W >= 64 && W <= 8192 && pitch >= W / 2 + 1 &&
+         (pitch % 16) == 0;
+}
+
+#define MC_FULL_SET_LDS(k, bytes) \
+  (void)hipFuncSetAttribute((const void*)(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))
+
+#define MC_FULL_DISPATCH(LOGV, LO, HI, ...)            \
+  switch (LOGV) {                                      \
+    case 5: if (LO <= 5 && 5 <= HI) { constexpr int L = 5; __VA_ARGS__ } break;    \
+    case 6: if (LO <= 6 && 6 <= HI) { constexpr int L = 6; __VA_ARGS__ } break;    \
+    case 7: if (LO <= 7 && 7 <= HI) { constexpr int L = 7; __VA_ARGS__ } break;    \
+    case 8: if (LO <= 8 && 8 <= HI) { constexpr int L = 8; __VA_ARGS__ } break;    \
+    case 9: if (LO <= 9 && 9 <= HI) { constexpr int L = 9; __VA_ARGS__ } break;    \
+    case 10: if (LO <= 10 && 10 <= HI) { constexpr int L = 10; __VA_ARGS__ } break; \
+    case 11: if (LO <= 11 && 11 <= HI) { constexpr int L = 11; __VA_ARGS__ } break; \
+    case 12: if (LO <= 12 && 12 <= HI) { constexpr int L = 12; __VA_ARGS__ } break; \
+    default: return MC_ERR_UNSUPPORTED;                \
+  }
+
+extern "C" {
+
+int mc_full_spectrum_pitch(int W) { return ((W / 2 + 1) + 15) & ~15; }
+
+int mc_full_rows_forward(const float* src, const int64_t* job_off, int64_t row_stride, void* S,
+                         const void* tw_row, int njobs, int H, int W, int pitch, void* stream) {
+  if (!src || !job_off || !S || !tw_row || njobs < 1) return MC_ERR_ARG;
+  if (!full_sizes_ok(H, W, pitch) || (reinterpret_cast<uintptr_t>(src) & 7) || (row_stride & 1)) return MC_ERR_UNSUPPORTED;
+  const int rows = 8;
+  dim3 grid((H + rows - 1) / rows, njobs);
+  MC_FULL_DISPATCH(mc_ilog2(W / 2), 5, 12, {
+    hipLaunchKernelGGL(full_rows_fwd<L>, grid, dim3(MC_WG), 0, (hipStream_t)stream, src, job_off, row_stride,
+                       (cfloat*)S, H, pitch, (const cfloat*)tw_row, rows);
+  });
+  return mc_check_launch();
+}
+
+int mc_full_rows_inverse(const void* S, float* out, const int64_t* out_off, int64_t out_stride,
+                         const void* tw_row, int njobs, int H, int W, int pitch, void* stream) {
+  if (!S || !out || !out_off || !tw_row || njobs < 1) return MC_ERR_ARG;
+  if (!full_sizes_ok(H, W, pitch) || (reinterpret_cast<uintptr_t>(out) & 7) || (out_stride & 1)) return MC_ERR_UNSUPPORTED;
+  const int rows = 8;
+  dim3 grid((H + rows - 1) / rows, njobs);
+  MC_FULL_DISPATCH(mc_ilog2(W / 2), 5, 12, {
+    hipLaunchKernelGGL(full_rows_inv<L>, grid, dim3(MC_WG), 0, (hipStream_t)stream, (const cfloat*)S, out, out_off,
+                       out_stride, H, pitch, (const cfloat*)tw_row, rows);
+  });
+  return mc_check_launch();
+}
+
+int mc_full_cols_shift(void* S, const float* shifts, const void* tw_col, float scale, int njobs, int H, int W,
+                       int pitch, void* stream) {
+  if (!S || !shifts || !tw_col || njobs < 1) return MC_ERR_ARG;
+  if (!full_sizes_ok(H, W, pitch)) return MC_ERR_UNSUPPORTED;
+  const size_t lds = 2 * sizeof(cfloat) * (size_t)lds_len(H);
+  dim3 grid(pitch / 2, njobs);
+  if (H == 4096) {
+    hipLaunchKernelGGL(full_cols_shift_r16, grid, dim3(MC_WG), 0, (hipStream_t)stream, (cfloat*)S, W, pitch,
+                       (const cfloat*)tw_col, shifts, scale);
+    return mc_check_launch();
+  }
+  MC_FULL_DISPATCH(mc_ilog2(H), 8, 11, {
+    auto k = full_cols_shift<L>;
+    MC_FULL_SET_LDS(k, lds);
+    hipLaunchKernelGGL(k, grid, dim3(MC_WG), lds, (hipStream_t)stream, (cfloat*)S, W, pitch, (const cfloat*)tw_col,
+                       shifts, scale);
+  });
+  return mc_check_launch();
+}
+
+int mc_full_cols_dose(const void* S, int nframes, int frame0, int total_frames, void* A, const void* tw_col,
+                      int H, int W, int pitch, float pixel_size, float pre_exposure, float dose_per_frame,
+                      float voltage, int first, int last, float scale, void* stream) {
+  if (!S || !A || !tw_col || nframes < 1 || frame0 < 0 || total_frames < frame0 + nframes || !(pixel_size > 0.f) ||
+      !(dose_per_frame >= 0.f))
+    return MC_ERR_ARG;
+  if (!full_sizes_ok(H, W, pitch)) return MC_ERR_UNSUPPORTED;
+  const float vscale = voltage >= 300.f ? 1.0f : (voltage >= 200.f ? 0.8f : 0.75f);
+  const size_t lds = 2 * sizeof(cfloat) * (size_t)lds_len(H);
+  dim3 grid(pitch / 2);
+  if (H == 4096) {
+    hipLaunchKernelGGL(full_cols_dose_r16, grid, dim3(MC_WG), 0, (hipStream_t)stream, (const cfloat*)S, nframes,
+                       frame0, total_frames, (cfloat*)A, W, pitch, (const cfloat*)tw_col, pixel_size, pre_exposure,
+                       dose_per_frame, vscale, first, last, scale);
+    return mc_check_launch();
+  }
+  MC_FULL_DISPATCH(mc_ilog2(H), 8, 11, {
+    auto k = full_cols_dose<L>;
+    MC_FULL_SET_LDS(k, lds);
+    hipLaunchKernelGGL(k, grid, dim3(MC_WG), lds, (hipStream_t)stream, (const cfloat*)S, nframes, frame0,
+                       total_frames, (cfloat*)A, W, pitch, (const cfloat*)tw_col, pixel_size, pre_exposure,
+                       dose_per_frame, vscale, first, last, scale);
+  });
+  return mc_check_launch();
+}
+
+}  // extern "C"

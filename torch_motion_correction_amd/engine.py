@@ -586,6 +586,70 @@ def _fourier_shift_polyphase(img, shifts):
     return out
 
 
+FULL_ROW_MAJOR = True  # tests: False forces the pruned engine's transposed layout on power-of-two frames
+
+
+def _full_row_major_ok(h, w):
+    """Power-of-two frames take the row-major full-spectrum kernels (csrc/full_fft.hip)."""
+    pow2 = lambda n: n > 0 and (n & (n - 1)) == 0
+    return FULL_ROW_MAJOR and pow2(h) and pow2(w) and 256 <= h <= 4096 and 64 <= w <= 8192
+
+
+def _fourier_shift_row_major(img, shifts):
+    """fourier_shift on power-of-two frames: rows forward -> (columns forward, phase ramp, columns
+    inverse) in one in-place kernel -> rows inverse, the spectrum row-major throughout."""
+    lib = _lib.load()
+    t, h, w = img.shape
+    dev = img.device
+    pitch = lib.mc_full_spectrum_pitch(w)
+    tw_row, tw_col = planmod.get_twiddles(w, dev), planmod.get_twiddles(h, dev)
+    out = torch.empty_like(img)
+    per_frame = h * pitch * 8
+    chunk = max(1, min(t, WORKSPACE_BYTES // per_frame))
+    S = torch.empty((chunk, h, pitch, 2), dtype=torch.float32, device=dev)
+    st = stream_ptr(dev)
+    shifts = shifts.to(dev, torch.float32).contiguous()
+    for a in range(0, t, chunk):
+        n = min(chunk, t - a)
+        off = torch.arange(a, a + n, device=dev, dtype=torch.int64) * (h * w)
+        check(lib.mc_full_rows_forward(ptr(img), ptr(off), w, ptr(S), ptr(tw_row), n, h, w, pitch, st),
+              "mc_full_rows_forward")
+        check(lib.mc_full_cols_shift(ptr(S), ptr(shifts[a:a + n]), ptr(tw_col), 1.0 / (h * w), n, h, w, pitch, st),
+              "mc_full_cols_shift")
+        check(lib.mc_full_rows_inverse(ptr(S), ptr(out), ptr(off), w, ptr(tw_row), n, h, w, pitch, st),
+              "mc_full_rows_inverse")
+    return out
+
+
+def _dose_weighted_sum_row_major(img, pixel_spacing, dose_per_frame, pre_exposure, voltage):
+    """dose_weighted_sum on power-of-two frames: rows forward per chunk, the exposure-weighted
+    accumulation inside the forward column pass (frame loop in registers), one inverse per movie."""
+    lib = _lib.load()
+    t, h, w = img.shape
+    dev = img.device
+    pitch = lib.mc_full_spectrum_pitch(w)
+    tw_row, tw_col = planmod.get_twiddles(w, dev), planmod.get_twiddles(h, dev)
+    per_frame = h * pitch * 8
+    chunk = max(1, min(t, WORKSPACE_BYTES // per_frame))
+    S = torch.empty((chunk, h, pitch, 2), dtype=torch.float32, device=dev)
+    A = torch.empty((h, pitch, 2), dtype=torch.float32, device=dev)
+    st = stream_ptr(dev)
+    for a in range(0, t, chunk):
+        n = min(chunk, t - a)
+        off = torch.arange(a, a + n, device=dev, dtype=torch.int64) * (h * w)
+        check(lib.mc_full_rows_forward(ptr(img), ptr(off), w, ptr(S), ptr(tw_row), n, h, w, pitch, st),
+              "mc_full_rows_forward")
+        check(lib.mc_full_cols_dose(ptr(S), n, a, t, ptr(A), ptr(tw_col), h, w, pitch, float(pixel_spacing),
+                                    float(pre_exposure), float(dose_per_frame), float(voltage),
+                                    1 if a == 0 else 0, 1 if a + n >= t else 0, 1.0 / (h * w), st),
+              "mc_full_cols_dose")
+    out = torch.empty((h, w), dtype=torch.float32, device=dev)
+    off0 = torch.zeros(1, device=dev, dtype=torch.int64)
+    check(lib.mc_full_rows_inverse(ptr(A), ptr(out), ptr(off0), w, ptr(tw_row), 1, h, w, pitch, st),
+          "mc_full_rows_inverse")
+    return out
+
+
 def fourier_shift(img, shifts):
     """irfft2(rfft2(img) * exp(-2 pi i (fy sy + fx sx))) per frame; shifts (t,2) px
     (correct_motion.py:484-496)."""
@@ -594,6 +658,8 @@ def fourier_shift(img, shifts):
     dev = img.device
     if POLYPHASE_FOURIER_SHIFT:
         return _fourier_shift_polyphase(img, shifts)
+    if _full_row_major_ok(h, w):
+        return _fourier_shift_row_major(img, shifts)
     try:
         g = planmod.full_geometry(h, w)
     except NotImplementedError:
@@ -701,6 +767,8 @@ def dose_weighted_sum(img, pixel_spacing, dose_per_frame, pre_exposure=0.0, volt
     dev = img.device
     if POLYPHASE_FOURIER_SHIFT:
         return _dose_weighted_sum_polyphase(img, pixel_spacing, dose_per_frame, pre_exposure, voltage)
+    if _full_row_major_ok(h, w):
+        return _dose_weighted_sum_row_major(img, pixel_spacing, dose_per_frame, pre_exposure, voltage)
     try:
         g = planmod.full_geometry(h, w)
     except NotImplementedError:
