@@ -309,10 +309,12 @@ int mc_pixel_shifts(const float* lattice, int GH, int GW, int h, int w, float pi
 int mc_pixel_shifts_at(const float* lattice, int GH, int GW, int h, int w, float pixel_spacing,
                        const float* coords_yx, int64_t n, float* out, void* stream);
 
-/* ---- full-spectrum transforms with a row-major spectrum (power-of-two sizes) ---------------
+/* ---- full-spectrum transforms with a row-major spectrum -------------------------------------
  * What correct_motion_fast (correct_motion.py:484-496) and the exposure-filtered sum
- * (examples/ttMotion.py:331-351) run on when H and W are powers of two (256 <= H <= 4096,
- * 64 <= W <= 8192; MC_ERR_UNSUPPORTED otherwise: use the pruned-engine entry points below).
+ * (examples/ttMotion.py:331-351) run on for rows of W = 64 .. 8192 (powers of two), 5760 or 11520
+ * columns and columns of H = 256 .. 4096 (powers of two), 4092 or 8184 rows -- any combination;
+ * the K3 formats 4092 x 5760 and 8184 x 11520 are transformed by mixed-radix passes (radix 31, 11,
+ * 8, 5, 3), no chirp-z.  MC_ERR_UNSUPPORTED otherwise: use the pruned-engine entry points below.
  * S[job][y][pitch] complex, pitch = mc_full_spectrum_pitch(W) = W/2 + 1 rounded up to 16.
  *   mc_full_rows_forward   rfft along x of njobs frames (origin src + job_off[j], rows row_stride
  *                          floats apart) -> S

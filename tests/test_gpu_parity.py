@@ -1627,7 +1627,11 @@ def test_evaluate_deformation_field_on_scattered_points(mc, dev):
 
 
 @pytest.mark.parametrize("shape", [(3, 256, 64), (2, 256, 256), (2, 512, 1024), (3, 1024, 512), (2, 2048, 256),
-                                   (2, 4096, 128), (1, 256, 8192), (2, 4096, 4096)])
+                                   (2, 4096, 128), (1, 256, 8192), (2, 4096, 4096),
+                                   # K3 formats: 5760 / 11520 columns (2^a 3^2 5), 4092 / 8184 rows (2^a 3 11 31:
+                                   # radix-31 and radix-11 passes), alone and together
+                                   (2, 256, 5760), (1, 512, 11520), (3, 4092, 64), (2, 8184, 128),
+                                   (2, 4092, 5760), (1, 8184, 11520)])
 def test_row_major_fourier_shift(mc, dev, shape):
     """correct_motion_fast on power-of-two frames (rows forward, one in-place column kernel for
     forward + phase ramp + inverse, rows inverse; spectrum row-major) against the oracle, against
@@ -1654,7 +1658,10 @@ def test_row_major_fourier_shift(mc, dev, shape):
 
 @pytest.mark.parametrize("shape,ps,dose,pre,kv", [((6, 256, 256), 1.0, 1.5, 0.0, 300.0),
                                                   ((5, 512, 256), 1.3, 0.8, 2.0, 200.0),
-                                                  ((3, 256, 1024), 0.83, 2.5, 0.5, 100.0)])
+                                                  ((3, 256, 1024), 0.83, 2.5, 0.5, 100.0),
+                                                  ((5, 4092, 64), 1.0, 1.2, 0.0, 300.0),
+                                                  ((4, 8184, 128), 0.5, 0.9, 1.0, 300.0),
+                                                  ((3, 256, 5760), 1.1, 1.0, 0.0, 200.0)])
 def test_row_major_dose_weighted_sum(mc, dev, shape, ps, dose, pre, kv):
     """The exposure-filtered sum with the weighted accumulation inside the forward column pass
     (frame loop in registers, chunks of frames carried through A) against the oracle and against

@@ -1,4 +1,4 @@
-// Full-spectrum 2-D real transforms with a ROW-MAJOR spectrum, power-of-two sizes: what
+// Full-spectrum 2-D real transforms with a ROW-MAJOR spectrum: what
 // correct_motion_fast (correct_motion.py:484-496: rfftn -> fourier_shift_dft_2d -> irfftn) and the
 // exposure-filtered frame sum (examples/ttMotion.py:331-351: rfft2 -> dose_weight_movie -> irfft2 ->
 // sum) run on.
@@ -20,10 +20,17 @@
 //   full_cols_dose  cols:  sum_f q_f(k) FFT_H(S_f column) accumulated in registers over the frames
 //                          of a chunk (+ A) -> A; on the last chunk / sqrt(sum q^2), IFFT(H), / (H W)
 //   full_rows_inv   rows:  S[job][y][0..W/2] -> c2r pack -> IFFT(W/2) -> real rows
+//
+// Sizes: rows of W = 64 .. 8192 (powers of two), 5760 and 11520 columns (W / 2 = 2^a 3^2 5);
+// columns of H = 256 .. 4096 (powers of two), 4092 and 8184 rows (2^a 3 11 31: radix-31 and radix-11
+// passes, mc_fft.h) -- the K3 detector's two frame formats (BASELINE configs 3 and 5) run here
+// without chirp-z.  Columns of more than 4096 rows go one column per workgroup (NC = 1).
 #include "mc_fft.h"
 #include "mcorr.h"
 
 // blockIdx.x -> column pair: the 8 pairs of one 128-byte line group on one XCD, consecutively
+// (single columns, NC = 1: the same with 16 columns per group -- npairs is then the column count / 2
+// and the caller maps block b to column 2 * full_pair_of_block(b >> 1, ..) + (b & 1))
 __device__ __forceinline__ int full_pair_of_block(int b, int npairs) {
   const int ngroups = (npairs + 7) / 8;
   if (ngroups < 8) return b;  // tiny widths: no mapping
@@ -36,13 +43,22 @@ __device__ __forceinline__ int full_pair_of_block(int b, int npairs) {
   return G * 8 + within;
 }
 
-template <int LOGN>
+// The lane index, made opaque: every transform of a kernel derives its addresses and twiddle indices
+// from its own copy, so the compiler cannot keep one transform's twiddles and addresses alive for the
+// next (common-subexpression elimination across the unrolled column / direction loops cost 380
+// registers for a 4092-point column pair).
+__device__ __forceinline__ int full_opaque(int t) {
+  asm volatile("" : "+v"(t));
+  return t;
+}
+
+template <int N>
 __global__ __launch_bounds__(MC_WG) void full_rows_fwd(const float* __restrict__ src,
                                                        const int64_t* __restrict__ job_off,
                                                        int64_t row_stride, cfloat* __restrict__ S, int H,
                                                        int pitch, const cfloat* __restrict__ tw_row,
                                                        int rows_per_wg) {
-  constexpr int N = 1 << LOGN;  // complex points = W / 2
+  // N complex points = W / 2
   __shared__ __attribute__((aligned(16))) cfloat line[lds_len(N)];
   const int tid = threadIdx.x;
   const int job = blockIdx.y;
@@ -56,13 +72,13 @@ __global__ __launch_bounds__(MC_WG) void full_rows_fwd(const float* __restrict__
       return cmake(v.x, v.y);
     };
     auto keep = [&](int k, cfloat v) { line[lpad(k)] = v; };
-    wg_fft<N, -1>(line, tid, tw_row, 2, load, keep);
+    wg_fft_any<N, -1>(line, (N & (N - 1)) ? full_opaque(tid) : tid, tw_row, 2, load, keep);
     __syncthreads();
     // real-FFT unpack: X[k] = (Z[k] + conj(Z[N-k]))/2 - i/2 * w^k * (Z[k] - conj(Z[N-k])), k = 0..N
     cfloat* out = S + ((int64_t)job * H + y) * pitch;
     for (int k = tid; k <= N; k += MC_WG) {
-      const cfloat zk = line[lpad(k & (N - 1))];
-      const cfloat zm = cconj(line[lpad((N - k) & (N - 1))]);
+      const cfloat zk = line[lpad(k == N ? 0 : k)];
+      const cfloat zm = cconj(line[lpad(k == 0 ? 0 : N - k)]);
       const cfloat sm = cadd(zk, zm), d = csub(zk, zm);
       const cfloat w = (k < N) ? tw_row[k] : cmake(-1.f, 0.f);
       const cfloat wd = cmul(w, d);  // -i*wd = (wd.y, -wd.x)
@@ -72,14 +88,14 @@ __global__ __launch_bounds__(MC_WG) void full_rows_fwd(const float* __restrict__
   }
 }
 
-template <int LOGN>
+template <int N>
 __global__ __launch_bounds__(MC_WG) void full_rows_inv(const cfloat* __restrict__ S, float* __restrict__ out,
                                                        const int64_t* __restrict__ out_off, int64_t out_stride,
                                                        int H, int pitch, const cfloat* __restrict__ tw_row,
                                                        int rows_per_wg) {
-  constexpr int N = 1 << LOGN;
-  __shared__ __attribute__((aligned(16))) cfloat line[lds_len(N)];
-  __shared__ __attribute__((aligned(16))) cfloat xs[N + 16];
+  extern __shared__ __attribute__((aligned(16))) char smem_fr[];
+  cfloat* line = reinterpret_cast<cfloat*>(smem_fr);  // lds_len(N)
+  cfloat* xs = line + lds_len(N) + 1;                 // N + 1 bins of the row
   const int tid = threadIdx.x;
   const int job = blockIdx.y;
   for (int r = 0; r < rows_per_wg; ++r) {
@@ -104,7 +120,7 @@ __global__ __launch_bounds__(MC_WG) void full_rows_inv(const cfloat* __restrict_
     };
     float* orow = out + out_off[job] + (int64_t)y * out_stride;
     auto store = [&](int n, cfloat v) { *reinterpret_cast<float2*>(orow + 2 * n) = make_float2(v.x, v.y); };
-    wg_fft<N, +1>(line, tid, tw_row, 2, load, store);
+    wg_fft_any<N, +1>(line, (N & (N - 1)) ? full_opaque(tid) : tid, tw_row, 2, load, store);
     __syncthreads();  // xs and the line are rewritten by the next row
   }
 }
@@ -115,47 +131,71 @@ __device__ __forceinline__ float full_fy(int ky, int H) {
   return (float)kk * (float)(1.0 / (double)H);
 }
 
-template <int LOGH>
-__global__ __launch_bounds__(MC_WG) void full_cols_shift(cfloat* __restrict__ S, int W, int pitch,
+// first column of workgroup b (NC columns per workgroup), ncols = pitch
+template <int NC>
+__device__ __forceinline__ int full_col_of_block(int b, int pitch) {
+  if constexpr (NC == 2) return 2 * full_pair_of_block(b, pitch / 2);
+  else return 2 * full_pair_of_block(b >> 1, pitch / 2) + (b & 1);
+}
+
+// stage NC adjacent columns of S (rows `pitch` apart) into NC LDS lines / write them back
+template <int H, int NC, int WG>
+__device__ __forceinline__ void full_cols_load(cfloat* const* lines, const cfloat* base, int pitch, int tid) {
+  for (int i = tid; i < H; i += WG) {
+    if constexpr (NC == 2) {
+      const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)i * pitch);
+      lines[0][lpad(i)] = cmake(v.x, v.y);
+      lines[1][lpad(i)] = cmake(v.z, v.w);
+    } else {
+      lines[0][lpad(i)] = base[(int64_t)i * pitch];
+    }
+  }
+}
+template <int H, int NC, int WG>
+__device__ __forceinline__ void full_cols_store(cfloat* const* lines, cfloat* base, int pitch, int tid) {
+  for (int i = tid; i < H; i += WG) {
+    if constexpr (NC == 2) {
+      const cfloat a = lines[0][lpad(i)], b = lines[1][lpad(i)];
+      *reinterpret_cast<float4*>(base + (int64_t)i * pitch) = make_float4(a.x, a.y, b.x, b.y);
+    } else {
+      base[(int64_t)i * pitch] = lines[0][lpad(i)];
+    }
+  }
+}
+
+template <int H, int NC, int WG>
+__global__ __launch_bounds__(WG) void full_cols_shift(cfloat* __restrict__ S, int W, int pitch,
                                                          const cfloat* __restrict__ tw_col,
                                                          const float* __restrict__ shifts, float scale) {
-  constexpr int H = 1 << LOGH;
   extern __shared__ __attribute__((aligned(16))) char smem_fc[];
   cfloat* lines[2] = {reinterpret_cast<cfloat*>(smem_fc), reinterpret_cast<cfloat*>(smem_fc) + lds_len(H)};
   const int tid = threadIdx.x;
-  const int npairs = pitch / 2;
-  const int kx0 = 2 * full_pair_of_block(blockIdx.x, npairs);
+  const int kx0 = full_col_of_block<NC>(blockIdx.x, pitch);
+  if (kx0 > W / 2) return;  // padding columns of the pitch (workgroup-uniform)
   const int job = blockIdx.y;
   cfloat* base = S + (int64_t)job * H * pitch + kx0;
-  for (int i = tid; i < H; i += MC_WG) {
-    const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)i * pitch);
-    lines[0][lpad(i)] = cmake(v.x, v.y);
-    lines[1][lpad(i)] = cmake(v.z, v.w);
-  }
+  full_cols_load<H, NC, WG>(lines, base, pitch, tid);
   __syncthreads();
   const float sy = shifts[2 * job], sx = shifts[2 * job + 1];
   const float m2pi = -6.283185307179586f;
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
+  for (int c = 0; c < NC; ++c) {
     cfloat* line = lines[c];
     const float fx = (float)(kx0 + c) * (float)(1.0 / (double)W);  // torch.fft.rfftfreq: k * (1/n)
     auto rd = [&](int i) { return line[lpad(i)]; };
     auto ramp = [&](int ky, cfloat v) {
       const float ang = (m2pi * full_fy(ky, H)) * sy + (m2pi * fx) * sx;
       float sn, cs;
-      sincosf(ang, &sn, &cs);
+      mc_sincos(ang, &sn, &cs);
       line[lpad(ky)] = cscale(cmul(v, cmake(cs, sn)), scale);
     };
-    wg_fft_inplace<H, -1>(line, tid, tw_col, 1, rd, ramp);
+    wg_fft_any_inplace<H, -1, WG>(line, full_opaque(tid), tw_col, 1, rd, ramp);
     __syncthreads();
     auto back = [&](int y, cfloat v) { line[lpad(y)] = v; };
-    wg_fft_inplace<H, +1>(line, tid, tw_col, 1, rd, back);
+    wg_fft_any_inplace<H, +1, WG>(line, full_opaque(tid), tw_col, 1, rd, back);
     __syncthreads();
   }
-  for (int i = tid; i < H; i += MC_WG) {
-    const cfloat a = lines[0][lpad(i)], b = lines[1][lpad(i)];
-    *reinterpret_cast<float4*>(base + (int64_t)i * pitch) = make_float4(a.x, a.y, b.x, b.y);
-  }
+  full_cols_store<H, NC, WG>(lines, base, pitch, tid);
 }
 
 // Exposure filter of examples/ttMotion.py:331-351 (crit_exposure_bfactor = -1), as dose_accumulate_kernel
@@ -169,50 +209,59 @@ __device__ __forceinline__ float full_dose_mh(int kx, int ky, int W, int H, floa
   return -0.5f / ncrit;
 }
 
-template <int LOGH>
-__global__ __launch_bounds__(MC_WG) void full_cols_dose(const cfloat* __restrict__ S, int nframes, int frame0,
+// radix of the last pass of a mixed-radix length-H transform; outputs the last pass hands to one
+// thread (per column)
+template <int H>
+__host__ __device__ constexpr int full_last_radix() {
+  int ns = 1, r = 1;
+  while (ns < H) {
+    r = smooth_radix(H / ns);
+    ns *= r;
+  }
+  return r;
+}
+template <int H, int WG>
+__host__ __device__ constexpr int full_last_slots() {
+  if ((H & (H - 1)) == 0) return (H / MC_WG) > 8 ? (H / MC_WG) : 8;  // 512 / 256 points: radix 8 / 4 on 64 threads
+  constexpr int r = full_last_radix<H>();
+  return ((H / r + WG - 1) / WG) * r;  // iterations of the last pass x its radix
+}
+
+template <int H, int NC, int WG>
+__global__ __launch_bounds__(WG) void full_cols_dose(const cfloat* __restrict__ S, int nframes, int frame0,
                                                         int total_frames, cfloat* __restrict__ A, int W,
                                                         int pitch, const cfloat* __restrict__ tw_col,
                                                         float pixel_size, float pre_exposure,
                                                         float dose_per_frame, float vscale, int first, int last,
                                                         float scale) {
-  constexpr int H = 1 << LOGH;
-  // outputs the last pass hands to one thread: H / 256 for H >= 1024; for 512 / 256 points the last
-  // pass (radix 8 / 4) runs on 64 threads that get 8 / 4 outputs each
-  constexpr int SLOTS = (H / MC_WG) > 8 ? (H / MC_WG) : 8;
+  constexpr int SLOTS = full_last_slots<H, WG>();
   extern __shared__ __attribute__((aligned(16))) char smem_fc[];
   cfloat* lines[2] = {reinterpret_cast<cfloat*>(smem_fc), reinterpret_cast<cfloat*>(smem_fc) + lds_len(H)};
   const int tid = threadIdx.x;
-  const int npairs = pitch / 2;
-  const int kx0 = 2 * full_pair_of_block(blockIdx.x, npairs);
-  cfloat acc[2][SLOTS];
-  float mh[2][SLOTS];
-  int kys[SLOTS];
+  const int kx0 = full_col_of_block<NC>(blockIdx.x, pitch);
+  if (kx0 > W / 2) return;  // padding columns of the pitch (workgroup-uniform)
+  cfloat acc[NC][SLOTS];
+  float mh[NC][SLOTS];
+  int kys[SLOTS];  // output row of a slot (power-of-two lines: recorded; mixed radix: computed, see below)
   int nslots = 0;
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) kys[s] = 0;
 #pragma unroll
-  for (int c = 0; c < 2; ++c)
+  for (int c = 0; c < NC; ++c)
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
       acc[c][s] = cmake(0.f, 0.f);
       mh[c][s] = 0.f;
     }
   for (int j = 0; j < nframes; ++j) {
-    const cfloat* base = S + (int64_t)j * H * pitch + kx0;
-    for (int i = tid; i < H; i += MC_WG) {
-      const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)i * pitch);
-      lines[0][lpad(i)] = cmake(v.x, v.y);
-      lines[1][lpad(i)] = cmake(v.z, v.w);
-    }
+    full_cols_load<H, NC, WG>(lines, S + (int64_t)j * H * pitch + kx0, pitch, tid);
     __syncthreads();
     const float dose = pre_exposure + dose_per_frame * (float)(frame0 + j + 1);
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < NC; ++c) {
       cfloat* line = lines[c];
       auto rd = [&](int i) { return line[lpad(i)]; };
-      int slot = 0;  // the last pass calls `take` SLOTS times per thread, in a fixed (unrolled) order
-      auto take = [&](int ky, cfloat v) {
+      auto take3 = [&](int ky, cfloat v, int slot) {
         if (j == 0) {
           kys[slot] = ky;
           mh[c][slot] = full_dose_mh(kx0 + c, ky, W, H, pixel_size, vscale);
@@ -220,18 +269,30 @@ __global__ __launch_bounds__(MC_WG) void full_cols_dose(const cfloat* __restrict
         const float q = expf(mh[c][slot] * dose);
         acc[c][slot].x += q * v.x;
         acc[c][slot].y += q * v.y;
-        ++slot;
       };
-      wg_fft_inplace<H, -1>(line, tid, tw_col, 1, rd, take);
-      nslots = slot;
+      if constexpr ((H & (H - 1)) == 0) {
+        int slot = 0;  // the last pass calls `take` SLOTS times per thread, in a fixed (unrolled) order
+        auto take = [&](int ky, cfloat v) {
+          take3(ky, v, slot);
+          ++slot;
+        };
+        wg_fft_any_inplace<H, -1, WG>(line, full_opaque(tid), tw_col, 1, rd, take);
+        nslots = slot;
+      } else {
+        // mixed radix: the pass itself names the slot (iteration x radix + output), a compile-time
+        // constant at every call site; the last iteration only runs on the threads that have a butterfly
+        wg_fft_any_inplace<H, -1, WG>(line, full_opaque(tid), tw_col, 1, rd, take3);
+        constexpr int R = full_last_radix<H>();
+        nslots = (tid + (SLOTS / R - 1) * WG < H / R) ? SLOTS : SLOTS - R;
+      }
     }
     __syncthreads();  // the next frame overwrites the lines
   }
-  // accumulator column pair: add what earlier chunks left in A, on the last chunk "restore the power"
+  // accumulator columns: add what earlier chunks left in A, on the last chunk "restore the power"
   // (/ sqrt(sum_f q_f^2) over ALL frames), transform back and scale
   cfloat* abase = A + kx0;
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
+  for (int c = 0; c < NC; ++c) {
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
       if (s >= nslots) continue;
@@ -258,18 +319,15 @@ __global__ __launch_bounds__(MC_WG) void full_cols_dose(const cfloat* __restrict
   __syncthreads();
   if (last) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < NC; ++c) {
       cfloat* line = lines[c];
       auto rd = [&](int i) { return line[lpad(i)]; };
       auto back = [&](int y, cfloat v) { line[lpad(y)] = v; };
-      wg_fft_inplace<H, +1>(line, tid, tw_col, 1, rd, back);
+      wg_fft_any_inplace<H, +1, WG>(line, full_opaque(tid), tw_col, 1, rd, back);
       __syncthreads();
     }
   }
-  for (int i = tid; i < H; i += MC_WG) {
-    const cfloat a = lines[0][lpad(i)], b = lines[1][lpad(i)];
-    *reinterpret_cast<float4*>(abase + (int64_t)i * pitch) = make_float4(a.x, a.y, b.x, b.y);
-  }
+  full_cols_store<H, NC, WG>(lines, abase, pitch, tid);
 }
 
 // ---- H = 4096: the register-resident radix-16 transform (mc_fft.h: 16 x 16 x 16, three passes,
@@ -284,6 +342,7 @@ __global__ __launch_bounds__(MC_WG) void full_cols_shift_r16(cfloat* __restrict_
   __shared__ __attribute__((aligned(16))) cfloat line[H];
   const int tid = threadIdx.x;
   const int kx0 = 2 * full_pair_of_block(blockIdx.x, pitch / 2);
+  if (kx0 > W / 2) return;  // padding columns of the pitch (workgroup-uniform)
   const int job = blockIdx.y;
   cfloat* base = S + (int64_t)job * H * pitch + kx0;
   cfloat v[2][16];
@@ -302,7 +361,7 @@ __global__ __launch_bounds__(MC_WG) void full_cols_shift_r16(cfloat* __restrict_
     auto ramp = [&](int k, cfloat x) {
       const float ang = (m2pi * full_fy(k, H)) * sy + (m2pi * fx) * sx;
       float sn, cs;
-      sincosf(ang, &sn, &cs);
+      mc_sincos(ang, &sn, &cs);
       v[c][(k - tid) >> 8] = cscale(cmul(x, cmake(cs, sn)), scale);
     };
     wg_fft4096_r16<-1, 8, 8>(line, tid, tw_col, in, ramp);
@@ -327,6 +386,7 @@ __global__ __launch_bounds__(MC_WG) void full_cols_dose_r16(const cfloat* __rest
   __shared__ __attribute__((aligned(16))) cfloat line[H];
   const int tid = threadIdx.x;
   const int kx0 = 2 * full_pair_of_block(blockIdx.x, pitch / 2);
+  if (kx0 > W / 2) return;  // padding columns of the pitch (workgroup-uniform)
   cfloat acc[2][16];
   float mh[2][16];
 #pragma unroll
@@ -397,26 +457,44 @@ __global__ __launch_bounds__(MC_WG) void full_cols_dose_r16(const cfloat* __rest
         make_float4(acc[0][n1].x, acc[0][n1].y, acc[1][n1].x, acc[1][n1].y);
 }
 
+static bool full_rows_ok(int W) {
+  return (mc_is_pow2(W) && W >= 64 && W <= 8192) || W == 5760 || W == 11520;
+}
+static bool full_cols_ok(int H) { return (mc_is_pow2(H) && H >= 256 && H <= 4096) || H == 4092 || H == 8184; }
 static bool full_sizes_ok(int H, int W, int pitch) {
-  return mc_is_pow2(H) && mc_is_pow2(W) && H >= 256 && H <= 4096 && W >= 64 && W <= 8192 && pitch >= W / 2 + 1 &&
-         (pitch % 16) == 0;
+  return full_rows_ok(W) && full_cols_ok(H) && pitch >= W / 2 + 1 && (pitch % 16) == 0;
 }
 
 #define MC_FULL_SET_LDS(k, bytes) \
   (void)hipFuncSetAttribute((const void*)(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))
 
-#define MC_FULL_DISPATCH(LOGV, LO, HI, ...)            \
-  switch (LOGV) {                                      \
-    case 5: if (LO <= 5 && 5 <= HI) { constexpr int L = 5; __VA_ARGS__ } break;    \
-    case 6: if (LO <= 6 && 6 <= HI) { constexpr int L = 6; __VA_ARGS__ } break;    \
-    case 7: if (LO <= 7 && 7 <= HI) { constexpr int L = 7; __VA_ARGS__ } break;    \
-    case 8: if (LO <= 8 && 8 <= HI) { constexpr int L = 8; __VA_ARGS__ } break;    \
-    case 9: if (LO <= 9 && 9 <= HI) { constexpr int L = 9; __VA_ARGS__ } break;    \
-    case 10: if (LO <= 10 && 10 <= HI) { constexpr int L = 10; __VA_ARGS__ } break; \
-    case 11: if (LO <= 11 && 11 <= HI) { constexpr int L = 11; __VA_ARGS__ } break; \
-    case 12: if (LO <= 12 && 12 <= HI) { constexpr int L = 12; __VA_ARGS__ } break; \
-    default: return MC_ERR_UNSUPPORTED;                \
+#define MC_FULL_CASE(V, ...) \
+  case V: {                  \
+    constexpr int L = V;     \
+    __VA_ARGS__              \
+  } break;
+// complex points of a row line (W / 2)
+#define MC_FULL_DISPATCH_ROWS(NV, ...)                                                              \
+  switch (NV) {                                                                                     \
+    MC_FULL_CASE(32, __VA_ARGS__) MC_FULL_CASE(64, __VA_ARGS__) MC_FULL_CASE(128, __VA_ARGS__)      \
+    MC_FULL_CASE(256, __VA_ARGS__) MC_FULL_CASE(512, __VA_ARGS__) MC_FULL_CASE(1024, __VA_ARGS__)   \
+    MC_FULL_CASE(2048, __VA_ARGS__) MC_FULL_CASE(4096, __VA_ARGS__) MC_FULL_CASE(2880, __VA_ARGS__) \
+    MC_FULL_CASE(5760, __VA_ARGS__)                                                                 \
+    default: return MC_ERR_UNSUPPORTED;                                                             \
   }
+// rows of a column line (H) taken by the staged kernels (4096: the register-resident kernels)
+#define MC_FULL_DISPATCH_COLS(HV, ...)                                                             \
+  switch (HV) {                                                                                    \
+    MC_FULL_CASE(256, __VA_ARGS__) MC_FULL_CASE(512, __VA_ARGS__) MC_FULL_CASE(1024, __VA_ARGS__)  \
+    MC_FULL_CASE(2048, __VA_ARGS__) MC_FULL_CASE(4092, __VA_ARGS__) MC_FULL_CASE(8184, __VA_ARGS__) \
+    default: return MC_ERR_UNSUPPORTED;                                                            \
+  }
+// columns per workgroup: pairs while two lines fit twice into a CU's LDS, single columns above;
+// threads per workgroup: 512 for 8184 rows (264 radix-31 butterflies per column)
+template <int H>
+constexpr int full_nc() { return H > 4096 ? 1 : 2; }
+template <int H>
+constexpr int full_wg() { return H > 4096 ? 512 : MC_WG; }
 
 extern "C" {
 
@@ -428,7 +506,7 @@ int mc_full_rows_forward(const float* src, const int64_t* job_off, int64_t row_s
   if (!full_sizes_ok(H, W, pitch) || (reinterpret_cast<uintptr_t>(src) & 7) || (row_stride & 1)) return MC_ERR_UNSUPPORTED;
   const int rows = 8;
   dim3 grid((H + rows - 1) / rows, njobs);
-  MC_FULL_DISPATCH(mc_ilog2(W / 2), 5, 12, {
+  MC_FULL_DISPATCH_ROWS(W / 2, {
     hipLaunchKernelGGL(full_rows_fwd<L>, grid, dim3(MC_WG), 0, (hipStream_t)stream, src, job_off, row_stride,
                        (cfloat*)S, H, pitch, (const cfloat*)tw_row, rows);
   });
@@ -441,8 +519,11 @@ int mc_full_rows_inverse(const void* S, float* out, const int64_t* out_off, int6
   if (!full_sizes_ok(H, W, pitch) || (reinterpret_cast<uintptr_t>(out) & 7) || (out_stride & 1)) return MC_ERR_UNSUPPORTED;
   const int rows = 8;
   dim3 grid((H + rows - 1) / rows, njobs);
-  MC_FULL_DISPATCH(mc_ilog2(W / 2), 5, 12, {
-    hipLaunchKernelGGL(full_rows_inv<L>, grid, dim3(MC_WG), 0, (hipStream_t)stream, (const cfloat*)S, out, out_off,
+  MC_FULL_DISPATCH_ROWS(W / 2, {
+    auto k = full_rows_inv<L>;
+    const size_t lds = sizeof(cfloat) * ((size_t)lds_len(L) + 1 + L + 2);
+    MC_FULL_SET_LDS(k, lds);
+    hipLaunchKernelGGL(k, grid, dim3(MC_WG), lds, (hipStream_t)stream, (const cfloat*)S, out, out_off,
                        out_stride, H, pitch, (const cfloat*)tw_row, rows);
   });
   return mc_check_launch();
@@ -452,18 +533,18 @@ int mc_full_cols_shift(void* S, const float* shifts, const void* tw_col, float s
                        int pitch, void* stream) {
   if (!S || !shifts || !tw_col || njobs < 1) return MC_ERR_ARG;
   if (!full_sizes_ok(H, W, pitch)) return MC_ERR_UNSUPPORTED;
-  const size_t lds = 2 * sizeof(cfloat) * (size_t)lds_len(H);
-  dim3 grid(pitch / 2, njobs);
   if (H == 4096) {
-    hipLaunchKernelGGL(full_cols_shift_r16, grid, dim3(MC_WG), 0, (hipStream_t)stream, (cfloat*)S, W, pitch,
-                       (const cfloat*)tw_col, shifts, scale);
+    hipLaunchKernelGGL(full_cols_shift_r16, dim3(pitch / 2, njobs), dim3(MC_WG), 0, (hipStream_t)stream, (cfloat*)S,
+                       W, pitch, (const cfloat*)tw_col, shifts, scale);
     return mc_check_launch();
   }
-  MC_FULL_DISPATCH(mc_ilog2(H), 8, 11, {
-    auto k = full_cols_shift<L>;
+  MC_FULL_DISPATCH_COLS(H, {
+    constexpr int NC = full_nc<L>(), WG = full_wg<L>();
+    auto k = full_cols_shift<L, NC, WG>;
+    const size_t lds = NC * sizeof(cfloat) * (size_t)lds_len(L);
     MC_FULL_SET_LDS(k, lds);
-    hipLaunchKernelGGL(k, grid, dim3(MC_WG), lds, (hipStream_t)stream, (cfloat*)S, W, pitch, (const cfloat*)tw_col,
-                       shifts, scale);
+    hipLaunchKernelGGL(k, dim3(pitch / NC, njobs), dim3(WG), lds, (hipStream_t)stream, (cfloat*)S, W, pitch,
+                       (const cfloat*)tw_col, shifts, scale);
   });
   return mc_check_launch();
 }
@@ -476,18 +557,18 @@ int mc_full_cols_dose(const void* S, int nframes, int frame0, int total_frames, 
     return MC_ERR_ARG;
   if (!full_sizes_ok(H, W, pitch)) return MC_ERR_UNSUPPORTED;
   const float vscale = voltage >= 300.f ? 1.0f : (voltage >= 200.f ? 0.8f : 0.75f);
-  const size_t lds = 2 * sizeof(cfloat) * (size_t)lds_len(H);
-  dim3 grid(pitch / 2);
   if (H == 4096) {
-    hipLaunchKernelGGL(full_cols_dose_r16, grid, dim3(MC_WG), 0, (hipStream_t)stream, (const cfloat*)S, nframes,
-                       frame0, total_frames, (cfloat*)A, W, pitch, (const cfloat*)tw_col, pixel_size, pre_exposure,
-                       dose_per_frame, vscale, first, last, scale);
+    hipLaunchKernelGGL(full_cols_dose_r16, dim3(pitch / 2), dim3(MC_WG), 0, (hipStream_t)stream, (const cfloat*)S,
+                       nframes, frame0, total_frames, (cfloat*)A, W, pitch, (const cfloat*)tw_col, pixel_size,
+                       pre_exposure, dose_per_frame, vscale, first, last, scale);
     return mc_check_launch();
   }
-  MC_FULL_DISPATCH(mc_ilog2(H), 8, 11, {
-    auto k = full_cols_dose<L>;
+  MC_FULL_DISPATCH_COLS(H, {
+    constexpr int NC = full_nc<L>(), WG = full_wg<L>();
+    auto k = full_cols_dose<L, NC, WG>;
+    const size_t lds = NC * sizeof(cfloat) * (size_t)lds_len(L);
     MC_FULL_SET_LDS(k, lds);
-    hipLaunchKernelGGL(k, grid, dim3(MC_WG), lds, (hipStream_t)stream, (const cfloat*)S, nframes, frame0,
+    hipLaunchKernelGGL(k, dim3(pitch / NC), dim3(WG), lds, (hipStream_t)stream, (const cfloat*)S, nframes, frame0,
                        total_frames, (cfloat*)A, W, pitch, (const cfloat*)tw_col, pixel_size, pre_exposure,
                        dose_per_frame, vscale, first, last, scale);
   });

@@ -31,6 +31,19 @@ __device__ __forceinline__ cfloat cmul_i(cfloat a) {
   return DIR < 0 ? cfloat{a.y, -a.x} : cfloat{-a.y, a.x};
 }
 
+// sin / cos of an fp32 angle in radians on the transcendental unit (v_sin_f32 / v_cos_f32 take
+// revolutions): two-term Cody-Waite reduction of the angle AS GIVEN (the reference's own fp32 angle,
+// correct_motion.py:488-494 via fourier_shift_dft_2d), so the result is sin(ang) / cos(ang) to ~1e-6
+// absolute for |ang| < 1e5 -- a dozen instructions instead of the ~100 of sincosf.
+__device__ __forceinline__ void mc_sincos(float ang, float* sn, float* cs) {
+  const float k = rintf(ang * 0.15915494309189535f);
+  float r = __builtin_fmaf(-k, 6.28318548202514648f, ang);  // 2 pi rounded to fp32 ...
+  r = __builtin_fmaf(-k, -1.74845553e-07f, r);              // ... and the rest of it
+  const float rev = r * 0.15915494309189535f;
+  *sn = __builtin_amdgcn_sinf(rev);
+  *cs = __builtin_amdgcn_cosf(rev);
+}
+
 static inline int mc_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MC_OK : (int)e;

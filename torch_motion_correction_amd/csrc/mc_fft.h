@@ -14,6 +14,7 @@
 // (one pad element per 16: the strided writes of a radix-8 pass then fall on
 // distinct banks for ds_write_b64's 16-lane groups).
 #pragma once
+#include <type_traits>
 #include "mc_common.h"
 
 __device__ __forceinline__ int lpad(int i) { return i + (i >> 4); }
@@ -324,10 +325,11 @@ __device__ __forceinline__ void wg_fft_inplace(cfloat* line, int tid, const cflo
 }
 
 // =====================================================================================
-// Lengths N = 2^a 3^b 5^c ("smooth": 2880 and 5760 = half the 5760- and 11520-column rows of
-// K3 detectors, 5120 and 10240 as chirp-z lengths): the same one-line Stockham scheme as above
-// with radix-3 and radix-5 passes and sub-transform lengths that are no longer powers of two
-// (k = j mod NS instead of a mask).  Radices: 8 while N allows, then 4, 5, 3, 2.
+// Lengths N = 2^a 3^b 5^c 7^d 11^e 13^f 31^g ("smooth": 2880 and 5760 = half the 5760- and
+// 11520-column rows of K3 detectors, 4092 and 8184 = their row counts, 5120 and 10240 as chirp-z
+// lengths): the same one-line Stockham scheme as above with odd-radix passes and sub-transform
+// lengths that are no longer powers of two (k = j mod NS instead of a mask).  Radices: the primes
+// above 5 first (largest first), then 8 while N allows, then 4, 5, 3, 2.
 // tw = exp(-2 pi i k / (N tw_stride)).
 // =====================================================================================
 template <int DIR>
@@ -358,44 +360,123 @@ __device__ __forceinline__ void bfly5(cfloat* a) {
   a[3] = csub(m2, n2);
 }
 
+// cos / sin (2 pi j / R) at compile time (double-precision Taylor series on an argument reduced to
+// [-pi, pi]; 34 terms: the remainder is below 1e-17)
+constexpr double mc_cx_sincos(double x, bool want_sin) {
+  double term = want_sin ? x : 1.0, sum = term;
+  for (int k = want_sin ? 3 : 2; k < 70; k += 2) {
+    term *= -x * x / (double)((k - 1) * k);
+    sum += term;
+  }
+  return sum;
+}
+template <int R>
+struct PrimeTab {
+  float c[R], s[R];
+  constexpr PrimeTab() : c{}, s{} {
+    for (int j = 0; j < R; ++j) {
+      const int jj = j <= R / 2 ? j : j - R;  // angle in (-pi, pi]
+      const double x = 6.283185307179586476925286766559 * (double)jj / (double)R;
+      c[j] = (float)mc_cx_sincos(x, false);
+      s[j] = (float)mc_cx_sincos(x, true);
+    }
+  }
+};
+
+// Butterfly of an odd prime radix R (7, 11, 13, 31: 4092 = 2^2 3 11 31 and 8184 = 2^3 3 11 31 are the
+// row counts of K3 frames) as a direct DFT in its symmetric form: with s_m = a_m + a_{R-m},
+// d_m = a_m - a_{R-m},
+//   X_0 = a_0 + sum s_m,   X_{k}, X_{R-k} = (a_0 + sum_m cos(2 pi m k / R) s_m) -/+ DIR... i (sum_m sin(2 pi m k / R) d_m)
+// i.e. (R-1)^2 / 2 real-times-complex products instead of (R-1)^2 complex ones; the cos / sin values
+// are compile-time constants after unrolling.
+template <int R, int DIR>
+__device__ __forceinline__ void bfly_prime(cfloat* a) {
+  constexpr int HF = (R - 1) / 2;
+  constexpr PrimeTab<R> T{};
+  cfloat s[HF], d[HF];
+#pragma unroll
+  for (int m = 1; m <= HF; ++m) {
+    s[m - 1] = cadd(a[m], a[R - m]);
+    d[m - 1] = csub(a[m], a[R - m]);
+  }
+  const cfloat x0 = a[0];
+  cfloat tot = x0;
+#pragma unroll
+  for (int m = 0; m < HF; ++m) tot = cadd(tot, s[m]);
+  a[0] = tot;
+#pragma unroll
+  for (int k = 1; k <= HF; ++k) {
+    cfloat p = x0, q = cmake(0.f, 0.f);
+#pragma unroll
+    for (int m = 1; m <= HF; ++m) {
+      const float c = T.c[(m * k) % R], sn = T.s[(m * k) % R];
+      p.x = __builtin_fmaf(c, s[m - 1].x, p.x);
+      p.y = __builtin_fmaf(c, s[m - 1].y, p.y);
+      q.x = __builtin_fmaf(sn, d[m - 1].x, q.x);
+      q.y = __builtin_fmaf(sn, d[m - 1].y, q.y);
+    }
+    // sum_n a_n exp(DIR 2 pi i n k / R) = p + DIR i q
+    const cfloat iq = cmul_i<DIR>(q);
+    a[k] = cadd(p, iq);
+    a[R - k] = csub(p, iq);
+  }
+}
+
 template <int R, int DIR>
 __device__ __forceinline__ void bfly_any(cfloat* a) {
   if constexpr (R == 5) bfly5<DIR>(a);
   else if constexpr (R == 3) bfly3<DIR>(a);
+  else if constexpr (R == 7 || R == 11 || R == 13 || R == 31) bfly_prime<R, DIR>(a);
   else bfly<R, DIR>(a);
 }
 
+// radix of the next pass: the large primes first (the first pass has no twiddles), then 8, 4, 5, 3, 2
 __host__ __device__ constexpr int smooth_radix(int rem) {
-  return rem % 8 == 0 ? 8 : rem % 4 == 0 ? 4 : rem % 5 == 0 ? 5 : rem % 3 == 0 ? 3 : rem % 2 == 0 ? 2 : 0;
+  return rem % 31 == 0 ? 31 : rem % 13 == 0 ? 13 : rem % 11 == 0 ? 11 : rem % 7 == 0 ? 7 : rem % 8 == 0 ? 8
+       : rem % 4 == 0 ? 4 : rem % 5 == 0 ? 5 : rem % 3 == 0 ? 3 : rem % 2 == 0 ? 2 : 0;
 }
 __host__ __device__ constexpr bool is_smooth(int n) {
   while (n % 2 == 0) n /= 2;
   while (n % 3 == 0) n /= 3;
   while (n % 5 == 0) n /= 5;
+  while (n % 7 == 0) n /= 7;
+  while (n % 11 == 0) n /= 11;
+  while (n % 13 == 0) n /= 13;
+  while (n % 31 == 0) n /= 31;
   return n == 1;
 }
 
-template <int N, int R, int NS, int DIR, bool SYNC_MID, bool SYNC_END, typename Load, typename Store>
+template <int N, int R, int NS, int DIR, bool SYNC_MID, bool SYNC_END, int WG = MC_WG, typename Load, typename Store>
 __device__ __forceinline__ void smooth_pass(int tid, const cfloat* __restrict__ tw, int tw_stride,
                                             Load load, Store store) {
   constexpr int NB = N / R;
-  constexpr int IT = (NB + MC_WG - 1) / MC_WG;
+  constexpr int IT = (NB + WG - 1) / WG;
   cfloat v[IT][R];
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
-    const int j = tid + it * MC_WG;
+    const int j = tid + it * WG;
     if (j < NB) {
 #pragma unroll
       for (int m = 0; m < R; ++m) v[it][m] = load(j + m * NB);
       if constexpr (NS > 1) {
         const int k = j % NS;
-        cfloat w1 = tw[k * (N / (NS * R)) * tw_stride];
-        if (DIR > 0) w1.y = -w1.y;
-        cfloat wm = w1;
+        if constexpr (R > 8) {
+          // many powers: every twiddle from the table (k m < NS R, so the index stays below N)
 #pragma unroll
-        for (int m = 1; m < R; ++m) {
-          v[it][m] = cmul(v[it][m], wm);
-          if (m + 1 < R) wm = cmul(wm, w1);
+          for (int m = 1; m < R; ++m) {
+            cfloat wm = tw[k * m * (N / (NS * R)) * tw_stride];
+            if (DIR > 0) wm.y = -wm.y;
+            v[it][m] = cmul(v[it][m], wm);
+          }
+        } else {
+          cfloat w1 = tw[k * (N / (NS * R)) * tw_stride];
+          if (DIR > 0) w1.y = -w1.y;
+          cfloat wm = w1;
+#pragma unroll
+          for (int m = 1; m < R; ++m) {
+            v[it][m] = cmul(v[it][m], wm);
+            if (m + 1 < R) wm = cmul(wm, w1);
+          }
         }
       }
       bfly_any<R, DIR>(v[it]);
@@ -404,18 +485,23 @@ __device__ __forceinline__ void smooth_pass(int tid, const cfloat* __restrict__ 
   if (SYNC_MID) __syncthreads();
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
-    const int j = tid + it * MC_WG;
+    const int j = tid + it * WG;
     if (j < NB) {
       const int k = j % NS;
       const int base = (j - k) * R + k;
 #pragma unroll
-      for (int m = 0; m < R; ++m) store(base + m * NS, v[it][m]);
+      for (int m = 0; m < R; ++m) {
+        // a store functor may ask for the compile-time position (iteration, output) of the value
+        // among this thread's outputs of the pass: register accumulators indexed without scratch
+        if constexpr (std::is_invocable_v<Store, int, cfloat, int>) store(base + m * NS, v[it][m], it * R + m);
+        else store(base + m * NS, v[it][m]);
+      }
     }
   }
   if (SYNC_END) __syncthreads();
 }
 
-template <int N, int NS, int DIR, bool FIRST, bool FIRST_LDS = false, typename Load, typename Store>
+template <int N, int NS, int DIR, bool FIRST, bool FIRST_LDS = false, int WG = MC_WG, typename Load, typename Store>
 __device__ __forceinline__ void smooth_rec(cfloat* line, int tid, const cfloat* __restrict__ tw,
                                            int tw_stride, Load load, Store store) {
   constexpr int R = smooth_radix(N / NS);
@@ -424,31 +510,41 @@ __device__ __forceinline__ void smooth_rec(cfloat* line, int tid, const cfloat* 
   auto lds_load = [line](int i) { return line[lpad(i)]; };
   auto lds_store = [line](int i, cfloat v) { line[lpad(i)] = v; };
   if constexpr (FIRST && LAST) {
-    smooth_pass<N, R, NS, DIR, FIRST_LDS, false>(tid, tw, tw_stride, load, store);
+    smooth_pass<N, R, NS, DIR, FIRST_LDS, false, WG>(tid, tw, tw_stride, load, store);
   } else if constexpr (FIRST) {
-    smooth_pass<N, R, NS, DIR, FIRST_LDS, true>(tid, tw, tw_stride, load, lds_store);
-    smooth_rec<N, NS * R, DIR, false>(line, tid, tw, tw_stride, load, store);
+    smooth_pass<N, R, NS, DIR, FIRST_LDS, true, WG>(tid, tw, tw_stride, load, lds_store);
+    smooth_rec<N, NS * R, DIR, false, false, WG>(line, tid, tw, tw_stride, load, store);
   } else if constexpr (LAST) {
-    smooth_pass<N, R, NS, DIR, true, false>(tid, tw, tw_stride, lds_load, store);
+    smooth_pass<N, R, NS, DIR, true, false, WG>(tid, tw, tw_stride, lds_load, store);
   } else {
-    smooth_pass<N, R, NS, DIR, true, true>(tid, tw, tw_stride, lds_load, lds_store);
-    smooth_rec<N, NS * R, DIR, false>(line, tid, tw, tw_stride, load, store);
+    smooth_pass<N, R, NS, DIR, true, true, WG>(tid, tw, tw_stride, lds_load, lds_store);
+    smooth_rec<N, NS * R, DIR, false, false, WG>(line, tid, tw, tw_stride, load, store);
   }
 }
 
 // Length-N transform (any N = 2^a 3^b 5^c; powers of two take the plan-driven passes above) by
 // the whole workgroup; contract as wg_fft.
-template <int N, int DIR, typename Load, typename Store>
+// WG: threads of the workgroup (mixed-radix lengths only; 512 for the 8184-point columns, whose
+// radix-31 pass has 264 butterflies).
+template <int N, int DIR, int WG = MC_WG, typename Load, typename Store>
 __device__ __forceinline__ void wg_fft_any(cfloat* line, int tid, const cfloat* __restrict__ tw,
                                            int tw_stride, Load load, Store store) {
-  if constexpr ((N & (N - 1)) == 0) fft_rec<N, 1, DIR, true>(line, tid, tw, tw_stride, load, store);
-  else smooth_rec<N, 1, DIR, true>(line, tid, tw, tw_stride, load, store);
+  if constexpr ((N & (N - 1)) == 0) {
+    static_assert(WG == MC_WG, "power-of-two lines run on 256 threads");
+    fft_rec<N, 1, DIR, true>(line, tid, tw, tw_stride, load, store);
+  } else {
+    smooth_rec<N, 1, DIR, true, false, WG>(line, tid, tw, tw_stride, load, store);
+  }
 }
-template <int N, int DIR, typename Load, typename Store>
+template <int N, int DIR, int WG = MC_WG, typename Load, typename Store>
 __device__ __forceinline__ void wg_fft_any_inplace(cfloat* line, int tid, const cfloat* __restrict__ tw,
                                                    int tw_stride, Load load, Store store) {
-  if constexpr ((N & (N - 1)) == 0) fft_rec<N, 1, DIR, true, true>(line, tid, tw, tw_stride, load, store);
-  else smooth_rec<N, 1, DIR, true, true>(line, tid, tw, tw_stride, load, store);
+  if constexpr ((N & (N - 1)) == 0) {
+    static_assert(WG == MC_WG, "power-of-two lines run on 256 threads");
+    fft_rec<N, 1, DIR, true, true>(line, tid, tw, tw_stride, load, store);
+  } else {
+    smooth_rec<N, 1, DIR, true, true, WG>(line, tid, tw, tw_stride, load, store);
+  }
 }
 
 // Bluestein chirp-z: a length-n DFT (any n, 2n-1 <= M = power of two) of x as

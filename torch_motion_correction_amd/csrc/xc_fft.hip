@@ -1965,14 +1965,16 @@ __global__ __launch_bounds__(MC_WG) void xcg_peak_nbhd(const cfloat* __restrict_
 // bspec[M] = FFT_M(wrapped conj chirp) / M  (host, double precision, plan.py).
 // =====================================================================================
 // Line-engine codes of the xcg_* kernels' template parameter: 5..14 = chirp-z on M = 2^code points;
-// 20 / 21 = chirp-z on M = 5120 / 10240 (2^k 5); 22 / 23 = NO chirp, a direct mixed-radix transform
-// of the n = 2880 / 5760 = 2^a 3^2 5 points themselves (rows of 5760 / 11520 columns).
+// 20 / 21 = chirp-z on M = 5120 / 10240 (2^k 5); 22 .. 25 = NO chirp, a direct mixed-radix transform
+// of the n points themselves: 2880 / 5760 = 2^a 3^2 5 (rows of 5760 / 11520 columns), 4092 / 8184 =
+// 2^a 3 11 31 (their columns; radix 31 and 11 passes, mc_fft.h).
 __host__ __device__ constexpr int mc_line_m(int code) {
-  return code < 20 ? (1 << code) : code == 20 ? 5120 : code == 21 ? 10240 : code == 22 ? 2880 : code == 23 ? 5760 : 0;
+  return code < 20 ? (1 << code) : code == 20 ? 5120 : code == 21 ? 10240 : code == 22 ? 2880 : code == 23 ? 5760
+       : code == 24 ? 4092 : code == 25 ? 8184 : 0;
 }
 __host__ __device__ constexpr bool mc_line_direct(int code) { return code >= 22; }
 static int mc_line_code(int M, bool direct) {
-  if (direct) return M == 2880 ? 22 : M == 5760 ? 23 : -1;
+  if (direct) return M == 2880 ? 22 : M == 5760 ? 23 : M == 4092 ? 24 : M == 8184 ? 25 : -1;
   if (M == 5120) return 20;
   if (M == 10240) return 21;
   return mc_is_pow2(M) ? mc_ilog2(M) : -1;
@@ -1993,7 +1995,13 @@ template <int CODE, int DIR, typename Load, typename Store>
 __device__ __forceinline__ void xcg_line_fft(cfloat* line, int tid, const XcLine& ln, int n, Load load,
                                              Store store, int keep = 0) {
   constexpr int M = mc_line_m(CODE);
-  if constexpr (mc_line_direct(CODE)) wg_fft_any<M, DIR>(line, tid, ln.tw_m, 1, load, store);
+  if constexpr (mc_line_direct(CODE)) {
+    // the lane index made opaque per line: twiddles and addresses of the mixed-radix passes are then
+    // re-derived for every line instead of being hoisted out of the row loops into 100+ registers
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    wg_fft_any<M, DIR>(line, t, ln.tw_m, 1, load, store);
+  }
   else wg_bluestein<M>(line, tid, ln.tw_m, ln.chirp, ln.bspec, n, load, store, keep);
 }
 
@@ -2286,6 +2294,8 @@ __global__ __launch_bounds__(MC_WG) void xcg_rows_inv(
     MC_DISPATCH_CASE(21, __VA_ARGS__)        \
     MC_DISPATCH_CASE(22, __VA_ARGS__)        \
     MC_DISPATCH_CASE(23, __VA_ARGS__)        \
+    MC_DISPATCH_CASE(24, __VA_ARGS__)        \
+    MC_DISPATCH_CASE(25, __VA_ARGS__)        \
     default:                                 \
       return MC_ERR_UNSUPPORTED;             \
   }

@@ -590,9 +590,12 @@ FULL_ROW_MAJOR = True  # tests: False forces the pruned engine's transposed layo
 
 
 def _full_row_major_ok(h, w):
-    """Power-of-two frames take the row-major full-spectrum kernels (csrc/full_fft.hip)."""
+    """Frames the row-major full-spectrum kernels (csrc/full_fft.hip) take: power-of-two rows and
+    columns, and the K3 detector's 5760 / 11520 columns and 4092 / 8184 rows (mixed radix)."""
     pow2 = lambda n: n > 0 and (n & (n - 1)) == 0
-    return FULL_ROW_MAJOR and pow2(h) and pow2(w) and 256 <= h <= 4096 and 64 <= w <= 8192
+    rows_ok = (pow2(w) and 64 <= w <= 8192) or w in (5760, 11520)
+    cols_ok = (pow2(h) and 256 <= h <= 4096) or h in (4092, 8184)
+    return FULL_ROW_MAJOR and rows_ok and cols_ok
 
 
 def _fourier_shift_row_major(img, shifts):

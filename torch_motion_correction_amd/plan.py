@@ -144,7 +144,7 @@ def native_height(h: int) -> bool:
     return _is_pow2(h) and 16 <= h <= 4096
 
 
-DIRECT_LINE_LENGTHS = (2880, 5760)   # mixed-radix (2^a 3^2 5) lines transformed as they are: no chirp-z
+DIRECT_LINE_LENGTHS = (2880, 5760, 4092, 8184)   # mixed-radix lines (2^a 3^2 5; 2^a 3 11 31) transformed as they are: no chirp-z
 SMOOTH_CHIRP_LENGTHS = (5120, 10240)  # chirp-z lengths 2^k 5 next to the powers of two
 
 
