@@ -138,16 +138,38 @@ __device__ __forceinline__ int full_col_of_block(int b, int pitch) {
   else return 2 * full_pair_of_block(b >> 1, pitch / 2) + (b & 1);
 }
 
-// stage NC adjacent columns of S (rows `pitch` apart) into NC LDS lines / write them back
+// stage NC adjacent columns of S (rows `pitch` apart) into NC LDS lines / write them back.  All of a
+// thread's loads are issued before the first LDS write (a rolled loop waits for every load in turn:
+// H / WG memory round trips per column instead of one).
 template <int H, int NC, int WG>
 __device__ __forceinline__ void full_cols_load(cfloat* const* lines, const cfloat* base, int pitch, int tid) {
-  for (int i = tid; i < H; i += WG) {
-    if constexpr (NC == 2) {
-      const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)i * pitch);
-      lines[0][lpad(i)] = cmake(v.x, v.y);
-      lines[1][lpad(i)] = cmake(v.z, v.w);
-    } else {
-      lines[0][lpad(i)] = base[(int64_t)i * pitch];
+  constexpr int IT = (H + WG - 1) / WG;
+  if constexpr (NC == 2) {
+    float4 v[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int i = tid + it * WG;
+      if (i < H) v[it] = *reinterpret_cast<const float4*>(base + (int64_t)i * pitch);
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int i = tid + it * WG;
+      if (i < H) {
+        lines[0][lpad(i)] = cmake(v[it].x, v[it].y);
+        lines[1][lpad(i)] = cmake(v[it].z, v[it].w);
+      }
+    }
+  } else {
+    cfloat v[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int i = tid + it * WG;
+      if (i < H) v[it] = base[(int64_t)i * pitch];
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int i = tid + it * WG;
+      if (i < H) lines[0][lpad(i)] = v[it];
     }
   }
 }
@@ -263,7 +285,7 @@ __global__ __launch_bounds__(WG) void full_cols_dose(const cfloat* __restrict__ 
       auto rd = [&](int i) { return line[lpad(i)]; };
       auto take3 = [&](int ky, cfloat v, int slot) {
         if (j == 0) {
-          kys[slot] = ky;
+          if constexpr ((H & (H - 1)) == 0) kys[slot] = ky;
           mh[c][slot] = full_dose_mh(kx0 + c, ky, W, H, pixel_size, vscale);
         }
         const float q = expf(mh[c][slot] * dose);
@@ -297,7 +319,11 @@ __global__ __launch_bounds__(WG) void full_cols_dose(const cfloat* __restrict__ 
     for (int s = 0; s < SLOTS; ++s) {
       if (s >= nslots) continue;
       cfloat a = acc[c][s];
-      const int ky = kys[s];
+      int ky = kys[s];
+      if constexpr ((H & (H - 1)) != 0) {  // last mixed-radix pass: output j + m H/R of butterfly j = tid + it WG
+        constexpr int R = full_last_radix<H>();
+        ky = tid + (s / R) * WG + (s % R) * (H / R);
+      }
       if (!first) {
         const cfloat prev = abase[(int64_t)ky * pitch + c];
         a.x += prev.x;
@@ -564,7 +590,9 @@ int mc_full_cols_dose(const void* S, int nframes, int frame0, int total_frames, 
     return mc_check_launch();
   }
   MC_FULL_DISPATCH_COLS(H, {
-    constexpr int NC = full_nc<L>(), WG = full_wg<L>();
+    // mixed-radix columns: one column per workgroup (two columns' accumulators and exposure exponents
+    // on top of the radix-31 pass need 300 registers: one wavefront per SIMD)
+    constexpr int NC = (L & (L - 1)) ? 1 : full_nc<L>(), WG = full_wg<L>();
     auto k = full_cols_dose<L, NC, WG>;
     const size_t lds = NC * sizeof(cfloat) * (size_t)lds_len(L);
     MC_FULL_SET_LDS(k, lds);
