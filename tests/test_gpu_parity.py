@@ -778,6 +778,33 @@ def test_motion_correct_sum_with_dose_weighting(mc, dev):
     assert float((z - plain.sum(0).cpu() / 6**0.5).abs().max()) <= 1e-4 * float(z.abs().max())
 
 
+@pytest.mark.parametrize("rigid", [True, False])
+def test_motion_correct_sum_dose_weighting_streams_chunks(mc, dev, rigid):
+    """motion_correct_sum(dose_per_frame=...) without return_frames warps, transforms and weights the
+    movie a chunk of frames at a time (the corrected movie is never held): same sum as the
+    all-frames form and as the oracle's dose weighting of the corrected frames, with the workspace
+    squeezed to two frames per chunk (7 frames: a last chunk of one)."""
+    from torch_motion_correction_amd import engine
+
+    st, dy, dx = drift_stack(7, 256, 512, seed=21)
+    if rigid:
+        field = mc.estimate_global_motion(st.to(dev), 1.0)
+    else:
+        g = torch.Generator().manual_seed(5)
+        field = (torch.randn(2, 7, 3, 4, generator=g) * 1.5).to(dev)
+    whole, frames = mc.motion_correct_sum(st.to(dev), field, 1.0, return_frames=True, dose_per_frame=0.9,
+                                          pre_exposure=0.5, voltage=200.0)
+    try:
+        ws, engine.WORKSPACE_BYTES = engine.WORKSPACE_BYTES, 2 * 256 * (512 // 2 + 16) * 8
+        streamed = mc.motion_correct_sum(st.to(dev), field, 1.0, dose_per_frame=0.9, pre_exposure=0.5,
+                                         voltage=200.0)
+    finally:
+        engine.WORKSPACE_BYTES = ws
+    ref = oracle.dose_weighted_sum(frames.cpu(), 1.0, 0.9, pre_exposure=0.5, voltage=200.0)
+    assert float((streamed.cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    assert float((streamed - whole).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
 # ------------------------------------------------------------------ wave-per-row K1, patch rows
 
 

@@ -325,10 +325,14 @@ def motion_correct_sum(image, deformation_grid, pixel_spacing, grid_type="catmul
     if dose_per_frame is None:
         frames, total = engine.warp(img, lat, float(pixel_spacing), want_frames=return_frames, want_sum=True,
                                     rigid=rigid)
-    else:
+    elif return_frames:
         frames, _ = engine.warp(img, lat, float(pixel_spacing), want_frames=True, want_sum=False, rigid=rigid)
         total = engine.dose_weighted_sum(frames, float(pixel_spacing), float(dose_per_frame),
                                          float(pre_exposure), float(voltage))
+    else:  # the corrected movie is only an intermediate: warped and transformed a chunk at a time
+        frames = None
+        total = engine.warp_dose_weighted_sum(img, lat, float(pixel_spacing), rigid, float(dose_per_frame),
+                                              float(pre_exposure), float(voltage))
     return (total.to(out_dev), frames.to(out_dev)) if return_frames else total.to(out_dev)
 
 

@@ -624,11 +624,15 @@ def _fourier_shift_row_major(img, shifts):
     return out
 
 
-def _dose_weighted_sum_row_major(img, pixel_spacing, dose_per_frame, pre_exposure, voltage):
-    """dose_weighted_sum on power-of-two frames: rows forward per chunk, the exposure-weighted
-    accumulation inside the forward column pass (frame loop in registers), one inverse per movie."""
+def _dose_weighted_sum_row_major(img, pixel_spacing, dose_per_frame, pre_exposure, voltage, frames_of=None,
+                                 shape=None):
+    """dose_weighted_sum on the row-major kernels: rows forward per chunk, the exposure-weighted
+    accumulation inside the forward column pass (frame loop in registers), one inverse per movie.
+    `frames_of(a, n)` -> the (n, h, w) fp32 frames a .. a+n-1 (default: slices of `img`); a caller
+    that produces the frames on the fly (motion_correct_sum: warp a chunk, transform it, drop it)
+    never holds more than one chunk of corrected frames."""
     lib = _lib.load()
-    t, h, w = img.shape
+    t, h, w = img.shape if shape is None else shape
     dev = img.device
     pitch = lib.mc_full_spectrum_pitch(w)
     tw_row, tw_col = planmod.get_twiddles(w, dev), planmod.get_twiddles(h, dev)
@@ -639,18 +643,41 @@ def _dose_weighted_sum_row_major(img, pixel_spacing, dose_per_frame, pre_exposur
     st = stream_ptr(dev)
     for a in range(0, t, chunk):
         n = min(chunk, t - a)
-        off = torch.arange(a, a + n, device=dev, dtype=torch.int64) * (h * w)
-        check(lib.mc_full_rows_forward(ptr(img), ptr(off), w, ptr(S), ptr(tw_row), n, h, w, pitch, st),
+        if frames_of is None:
+            src, first = img, a
+        else:
+            src, first = frames_of(a, n), 0
+        off = torch.arange(first, first + n, device=dev, dtype=torch.int64) * (h * w)
+        check(lib.mc_full_rows_forward(ptr(src), ptr(off), w, ptr(S), ptr(tw_row), n, h, w, pitch, st),
               "mc_full_rows_forward")
         check(lib.mc_full_cols_dose(ptr(S), n, a, t, ptr(A), ptr(tw_col), h, w, pitch, float(pixel_spacing),
                                     float(pre_exposure), float(dose_per_frame), float(voltage),
                                     1 if a == 0 else 0, 1 if a + n >= t else 0, 1.0 / (h * w), st),
               "mc_full_cols_dose")
+        del src
     out = torch.empty((h, w), dtype=torch.float32, device=dev)
     off0 = torch.zeros(1, device=dev, dtype=torch.int64)
     check(lib.mc_full_rows_inverse(ptr(A), ptr(out), ptr(off0), w, ptr(tw_row), 1, h, w, pitch, st),
           "mc_full_rows_inverse")
     return out
+
+
+def warp_dose_weighted_sum(img, lattices, pixel_spacing, rigid, dose_per_frame, pre_exposure, voltage):
+    """correct_motion -> dose_weight -> sum (examples/ttMotion.py:318-351, 398) without the corrected
+    movie in memory: on the row-major sizes (powers of two, the K3 formats) the frames are warped,
+    transformed and weighted a chunk at a time (BASELINE C5: 60 x 8184 x 11520 -- 22.6 GB of
+    corrected fp32 frames are never allocated); other sizes warp everything first."""
+    t, h, w = img.shape
+    if POLYPHASE_FOURIER_SHIFT or not _full_row_major_ok(h, w):
+        frames, _ = warp(img, lattices, pixel_spacing, want_frames=True, want_sum=False, rigid=rigid)
+        return dose_weighted_sum(frames, pixel_spacing, dose_per_frame, pre_exposure, voltage)
+
+    def frames_of(a, n):
+        return warp(img[a:a + n], lattices[a:a + n], pixel_spacing, want_frames=True, want_sum=False,
+                    rigid=rigid)[0]
+
+    return _dose_weighted_sum_row_major(img, pixel_spacing, dose_per_frame, pre_exposure, voltage,
+                                        frames_of=frames_of, shape=(t, h, w))
 
 
 def fourier_shift(img, shifts):
