@@ -112,22 +112,26 @@ def test_unsupported_sizes_fail_loudly():
 
 
 def test_super_resolution_frames_fit_the_band_limited_transforms():
-    """8184 x 11520 (BASELINE config 5 frames): the rows (5760 = 2^7 3^2 5 complex points) are
-    transformed directly by the mixed-radix passes (round 2; chirp-z lines of 8192 / 16384 points
-    before), the columns (8184 = 2^3 3 11 31) run on chirp-z lines of 16384 points."""
+    """8184 x 11520 (BASELINE config 5 frames): the rows (5760 = 2^7 3^2 5 complex points) and the
+    columns (8184 = 2^3 3 11 31: radix-31 and radix-11 passes) are transformed directly by the
+    mixed-radix engine (round 2; chirp-z lines of 8192 / 16384 points before)."""
     low, high = plan.band_limits((300, 10), 1.0)
     g = plan.xc_geometry(8184, 11520, high, 8184 / 4, 8184 / 8)
     assert (g.nkx, g.kyp + g.kyn) == (1153, 1637) and g.RG >= 1 and 8184 % g.RG == 0
     fwd, _ = plan.line_plan(5760, -1, "cpu", keep=g.nkx + 1)
     inv, _ = plan.line_plan(5760, +1, "cpu")
     col, _ = plan.line_plan(8184, -1, "cpu")
-    assert (fwd.M, fwd.keep, inv.M, col.M) == (5760, 0, 5760, 16384)
-    try:  # the chirp-z plans are still there (other widths, and as the cross-check of the direct lines)
+    assert (fwd.M, fwd.keep, inv.M, col.M) == (5760, 0, 5760, 8184)
+    col4, _ = plan.line_plan(4092, +1, "cpu")
+    assert (col4.M, col4.keep) == (4092, 0)
+    try:  # the chirp-z plans are still there (other lengths, and as the cross-check of the direct lines)
         plan.USE_DIRECT_LINES = False
         plan._LINES.clear()
         fwd, _ = plan.line_plan(5760, -1, "cpu", keep=g.nkx + 1)
         inv, _ = plan.line_plan(5760, +1, "cpu")
-        assert (fwd.M, fwd.keep, inv.M) == (8192, g.nkx + 1, 16384)
+        col, _ = plan.line_plan(8184, -1, "cpu")
+        col4, _ = plan.line_plan(4092, +1, "cpu")
+        assert (fwd.M, fwd.keep, inv.M, col.M, col4.M) == (8192, g.nkx + 1, 16384, 16384, 8192)
     finally:
         plan.USE_DIRECT_LINES = True
         plan._LINES.clear()

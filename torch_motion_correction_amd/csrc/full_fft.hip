@@ -402,21 +402,24 @@ __global__ __launch_bounds__(MC_WG) void full_cols_shift_r16(cfloat* __restrict_
         make_float4(v[0][n1].x, v[0][n1].y, v[1][n1].x, v[1][n1].y);
 }
 
+template <int NC>
 __global__ __launch_bounds__(MC_WG) void full_cols_dose_r16(const cfloat* __restrict__ S, int nframes, int frame0,
                                                             int total_frames, cfloat* __restrict__ A, int W,
                                                             int pitch, const cfloat* __restrict__ tw_col,
                                                             float pixel_size, float pre_exposure,
                                                             float dose_per_frame, float vscale, int first, int last,
                                                             float scale) {
+  // NC = 1: one column per workgroup (8-byte loads; 130 registers instead of 256 + spills to AGPRs:
+  // three wavefronts per SIMD instead of one)
   constexpr int H = 4096;
   __shared__ __attribute__((aligned(16))) cfloat line[H];
   const int tid = threadIdx.x;
-  const int kx0 = 2 * full_pair_of_block(blockIdx.x, pitch / 2);
+  const int kx0 = full_col_of_block<NC>(blockIdx.x, pitch);
   if (kx0 > W / 2) return;  // padding columns of the pitch (workgroup-uniform)
-  cfloat acc[2][16];
-  float mh[2][16];
+  cfloat acc[NC][16];
+  float mh[NC][16];
 #pragma unroll
-  for (int c = 0; c < 2; ++c)
+  for (int c = 0; c < NC; ++c)
 #pragma unroll
     for (int k3 = 0; k3 < 16; ++k3) {
       acc[c][k3] = cmake(0.f, 0.f);
@@ -424,16 +427,20 @@ __global__ __launch_bounds__(MC_WG) void full_cols_dose_r16(const cfloat* __rest
     }
   for (int j = 0; j < nframes; ++j) {
     const cfloat* base = S + (int64_t)j * H * pitch + kx0;
-    cfloat v[2][16];
+    cfloat v[NC][16];
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {
-      const float4 q = *reinterpret_cast<const float4*>(base + (int64_t)(256 * n1 + tid) * pitch);
-      v[0][n1] = cmake(q.x, q.y);
-      v[1][n1] = cmake(q.z, q.w);
+      if constexpr (NC == 2) {
+        const float4 q = *reinterpret_cast<const float4*>(base + (int64_t)(256 * n1 + tid) * pitch);
+        v[0][n1] = cmake(q.x, q.y);
+        v[1][n1] = cmake(q.z, q.w);
+      } else {
+        v[0][n1] = base[(int64_t)(256 * n1 + tid) * pitch];
+      }
     }
     const float dose = pre_exposure + dose_per_frame * (float)(frame0 + j + 1);
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < NC; ++c) {
       auto in = [&](int n1, int) { return v[c][n1]; };
       auto take = [&](int k, cfloat x) {
         const int k3 = (k - tid) >> 8;
@@ -447,7 +454,7 @@ __global__ __launch_bounds__(MC_WG) void full_cols_dose_r16(const cfloat* __rest
   }
   cfloat* abase = A + kx0;
 #pragma unroll
-  for (int c = 0; c < 2; ++c)
+  for (int c = 0; c < NC; ++c)
 #pragma unroll
     for (int k3 = 0; k3 < 16; ++k3) {
       cfloat a = acc[c][k3];
@@ -470,7 +477,7 @@ __global__ __launch_bounds__(MC_WG) void full_cols_dose_r16(const cfloat* __rest
     }
   if (last) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < NC; ++c) {
       auto in = [&](int n1, int) { return acc[c][n1]; };
       auto back = [&](int k, cfloat x) { acc[c][(k - tid) >> 8] = x; };
       wg_fft4096_r16<+1, 8, 8>(line, tid, tw_col, in, back);
@@ -478,9 +485,13 @@ __global__ __launch_bounds__(MC_WG) void full_cols_dose_r16(const cfloat* __rest
     }
   }
 #pragma unroll
-  for (int n1 = 0; n1 < 16; ++n1)
-    *reinterpret_cast<float4*>(abase + (int64_t)(256 * n1 + tid) * pitch) =
-        make_float4(acc[0][n1].x, acc[0][n1].y, acc[1][n1].x, acc[1][n1].y);
+  for (int n1 = 0; n1 < 16; ++n1) {
+    if constexpr (NC == 2)
+      *reinterpret_cast<float4*>(abase + (int64_t)(256 * n1 + tid) * pitch) =
+          make_float4(acc[0][n1].x, acc[0][n1].y, acc[1][n1].x, acc[1][n1].y);
+    else
+      abase[(int64_t)(256 * n1 + tid) * pitch] = acc[0][n1];
+  }
 }
 
 static bool full_rows_ok(int W) {
@@ -584,7 +595,7 @@ int mc_full_cols_dose(const void* S, int nframes, int frame0, int total_frames, 
   if (!full_sizes_ok(H, W, pitch)) return MC_ERR_UNSUPPORTED;
   const float vscale = voltage >= 300.f ? 1.0f : (voltage >= 200.f ? 0.8f : 0.75f);
   if (H == 4096) {
-    hipLaunchKernelGGL(full_cols_dose_r16, dim3(pitch / 2), dim3(MC_WG), 0, (hipStream_t)stream, (const cfloat*)S,
+    hipLaunchKernelGGL(full_cols_dose_r16<1>, dim3(pitch), dim3(MC_WG), 0, (hipStream_t)stream, (const cfloat*)S,
                        nframes, frame0, total_frames, (cfloat*)A, W, pitch, (const cfloat*)tw_col, pixel_size,
                        pre_exposure, dose_per_frame, vscale, first, last, scale);
     return mc_check_launch();

@@ -356,7 +356,8 @@ __global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
     const float* __restrict__ src, const int64_t* __restrict__ job_off, int64_t row_stride,
     const float* __restrict__ mask, const float* __restrict__ mean_rstd, cfloat* __restrict__ T1,
     const cfloat* __restrict__ tw_row, XcGeom g, XcBox box, double* __restrict__ stats_acc,
-    const int2* __restrict__ chord) {
+    const int2* __restrict__ chord, int lines16) {
+  extern __shared__ __attribute__((aligned(16))) float4 park0[];  // lines16: [4 waves][nkx]
   __shared__ __attribute__((aligned(16))) cfloat slabs[4][WF_SLAB];
   __shared__ __attribute__((aligned(16))) cfloat tab[WF_TWA + WF_TWB + 256];
   const cfloat* twA = tab;
@@ -443,7 +444,11 @@ __global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
       int ts = t;
       wf_pin(ts, X[0][0].x);  // addresses: computed here, not carried across rows
       const WfLane L = wf_lane(ts);
-      float4* park = reinterpret_cast<float4*>(slab);  // [kx] = {even row, odd row}; 410 x 16 B <= 8 KiB
+      // lines16: the first round's bins wait in their own LDS area (park0, dynamic) until the second
+      // round is done, and T1[job][kx][16 rows] goes out as whole 128-byte lines (two 64-byte halves
+      // written 10 us apart merged in L2 only most of the time: 0.55 GB written for a 0.40 GB T1)
+      const bool hold = lines16 && nrows == 4 && rr == 1;
+      float4* park = hold ? park0 + wv * g.nkx : reinterpret_cast<float4*>(slab);  // [kx] = {even row, odd row}
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -451,18 +456,26 @@ __global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
           const int k = L.kbin[s] + 256 * k3;
           if (k < g.nkx) park[k] = make_float4(Xe[s][k3].x, Xe[s][k3].y, X[s][k3].x, X[s][k3].y);
         }
-      __syncthreads();
-      {
+      if (!hold) {  // workgroup-uniform
+        __syncthreads();
         int tj = threadIdx.x;
         wf_pin(tj, X[0][0].y);
-        const int r8 = r16 + (rr >> 1) * 8;
         const float4* parked = reinterpret_cast<const float4*>(&slabs[0][0]);
-        for (int j = tj; j < 4 * g.nkx; j += 256) {  // 4 lanes = the 64 bytes of one kx
-          const int kx = j >> 2, w = j & 3;
-          *reinterpret_cast<float4*>(out + (int64_t)kx * g.ny + r8 + 2 * w) = parked[w * (WF_SLAB / 2) + kx];
+        if (lines16 && nrows == 4) {
+          for (int j = tj; j < 8 * g.nkx; j += 256) {  // 8 lanes = the 128 bytes of one kx
+            const int kx = j >> 3, pc = j & 7, w = pc & 3;
+            const float4 v = (pc >> 2) ? parked[w * (WF_SLAB / 2) + kx] : park0[w * g.nkx + kx];
+            *reinterpret_cast<float4*>(out + (int64_t)kx * g.ny + r16 + 2 * pc) = v;
+          }
+        } else {
+          const int r8 = r16 + (rr >> 1) * 8;
+          for (int j = tj; j < 4 * g.nkx; j += 256) {  // 4 lanes = the 64 bytes of one kx
+            const int kx = j >> 2, w = j & 3;
+            *reinterpret_cast<float4*>(out + (int64_t)kx * g.ny + r8 + 2 * w) = parked[w * (WF_SLAB / 2) + kx];
+          }
         }
+        __syncthreads();
       }
-      __syncthreads();
     } else {
 #pragma unroll
       for (int s = 0; s < 4; ++s)
@@ -1479,6 +1492,11 @@ static int geom_from(const mc_xc_geom* q, XcGeom* g, bool rows_pow2 = true, bool
 static int g_col_engine = 0;  // mc_xc_col_engine(): 0 = automatic, 1 = always the radix-8 Stockham columns
 static int g_row_engine = 0;
 static bool mc_force_wg_rows() { return g_row_engine == 1; }
+// experiments: NAME=1 in the environment switches a default-off feature on
+static bool mc_env_on(const char* name) {
+  const char* v = getenv(name);
+  return v && v[0] == '1';
+}
 
 // The wave-per-row kernel reads samples and mask rows with 16-byte loads.  job_off[] lives
 // on the device: callers of the C ABI keep it a multiple of 4 floats whenever W == 4096
@@ -1531,10 +1549,23 @@ static int rows_forward_impl(const float* src, const int64_t* job_off, int64_t r
     // wave-per-row engine (mc_wave_fft.h); misaligned jobs take its element-wise loads
     const int ngroups = (g.ny + WF_ROWS_PER_WG - 1) / WF_ROWS_PER_WG;
     dim3 grid((ngroups + 7) / 8 * 8, njobs);  // linear id = x + gridDim.x * y, decoded in the kernel
+    // whole 128-byte lines of T1 (16 rows per kx) when the first round's bins fit next to the slabs
+    // with two workgroups per CU still resident, and every 16-row piece is line-aligned.  OFF by
+    // default (MC_K1_LINES16=1 enables it): it saves the 0.15 GB of write amplification (one stream:
+    // 2.00 -> 1.97 ms per 40 x 4096^2 step) but its 26 KB of extra LDS per workgroup keeps the warp's
+    // tiles of the other stream out of the CU: 1.74 -> 1.84 ms per step under the two-stream overlap.
+    const size_t park_bytes = (size_t)4 * g.nkx * 16;
+    const int lines16 = (mc_env_on("MC_K1_LINES16") && (g.ny % 16) == 0 && park_bytes <= 27 * 1024 &&
+                         ((reinterpret_cast<uintptr_t>(T1) & 127) == 0)) ? 1 : 0;
+    const size_t dyn = lines16 ? park_bytes : 0;
 #define MC_WAVE_LAUNCH(KEEP, ST, LO, HI, CL, PF)                                                  \
-  hipLaunchKernelGGL((xc_rows_fwd_wave<KEEP, ST, LO, HI, CL, PF>), grid, dim3(256), 0,            \
-                     (hipStream_t)stream, src, job_off, row_stride, mask, mean_rstd, (cfloat*)T1,   \
-                     (const cfloat*)tw_row, g, b, stats_acc, (const int2*)row_chord)
+  do {                                                                                            \
+    auto kw = xc_rows_fwd_wave<KEEP, ST, LO, HI, CL, PF>;                                         \
+    if (dyn) (void)hipFuncSetAttribute((const void*)kw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
+    hipLaunchKernelGGL(kw, grid, dim3(256), dyn, (hipStream_t)stream, src, job_off, row_stride, mask, \
+                       mean_rstd, (cfloat*)T1, (const cfloat*)tw_row, g, b, stats_acc,             \
+                       (const int2*)row_chord, lines16);                                           \
+  } while (0)
 #define MC_WAVE_PICK(KEEP, ST)                                                              \
   do {                                                                                      \
     if (g.x0 >= 256 && g.x0 <= 512 && g.x1 >= 3584 && g.x1 <= 3840 && row_chord)            \
