@@ -16,6 +16,7 @@
 // contraction in this file): at coordinates ~4096 one ulp is 2.4e-4 px, which is
 // visible at the 1e-4 parity bar.
 #pragma clang fp contract(off)
+#include <type_traits>
 #include <stdlib.h>
 #include "mc_common.h"
 #include "mcorr.h"
@@ -1656,9 +1657,15 @@ __global__ __launch_bounds__(RIGID_LANES* GW3_WAVES, 4) void warp_field3(FieldAr
         }
         __syncthreads();
       }
-      const bool interior = whole_tile && wy0 >= 0 && wy0 + nrows <= h && ax >= 0 &&
-                            ax + (HALF ? RIGID_LANES * 4 + 3 + 2 * mgx : 4 * nq) <= w;
+      const bool interior_rt = whole_tile && wy0 >= 0 && wy0 + nrows <= h && ax >= 0 &&
+                               ax + (HALF ? RIGID_LANES * 4 + 3 + 2 * mgx : 4 * nq) <= w;
       const int oy = 1 + wy0, ox = 1 + ax;
+      // The tile-frame's two bodies are separate instantiations: the interior one (no zero-outside
+      // test, no column predicate) is straight-line code for all of a wave's pixels, so the LDS reads
+      // of one pixel are scheduled under the arithmetic of another instead of every pixel ending in an
+      // exec-mask branch.
+      auto pixels = [&](auto interior_tag) {
+        constexpr bool interior = decltype(interior_tag)::value;
       // One pixel at a time.  (Measured alternatives, same results, none faster: the wave's two rows
       // statement by statement for two independent chains per lane, 3.2 ms instead of 2.96; the same
       // on 2-float vectors, i.e. v_pk_* instructions, 3.3 ms.  The kernel is bound by VALU issue at
@@ -1667,7 +1674,7 @@ __global__ __launch_bounds__(RIGID_LANES* GW3_WAVES, 4) void warp_field3(FieldAr
 #pragma unroll
       for (int r = 0; r < GW3_RW; ++r) {
         const int y = y0 + r;
-        if (y >= h) break;
+        if (!interior && y >= h) break;
         const int row = wave * GW3_RW + r;
         const float4 yc4 = make_float4(s_ycoef[row][0], s_ycoef[row][1], s_ycoef[row][2], s_ycoef[row][3]);
         const float* e0 = es + (s_ytap[row][0] - R0) * 256 + lane;
@@ -1714,6 +1721,9 @@ __global__ __launch_bounds__(RIGID_LANES* GW3_WAVES, 4) void warp_field3(FieldAr
           if (WRITE_SUM) acc[r][k] += o;
         }
       }
+      };
+      if (interior_rt) pixels(std::true_type{});
+      else pixels(std::false_type{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA of f+1 (and this frame's stores)
     __syncthreads();  // buffer bi is free again, buffer bi^1 is complete
