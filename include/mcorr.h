@@ -146,6 +146,7 @@ int mc_xc_row_engine(int mode);
 /* m0 = {mean of the n floats at x, 1, 1}: the provisional mean mc_xc_rows_forward_stats takes
  * (one small workgroup; any value near the true mean serves). */
 int mc_xc_provisional_mean(const float* x, int n, float* m0, void* stream);
+int mc_xc_provisional_mean_t(const void* x, int storage, int n, float* m0, void* stream);
 
 /* K1 with the normalisation statistics fused in (whole-frame jobs only): samples become
  * (x - m0[0]) * mask (m0: device float[3] = {provisional mean, 1, 1}); while reading, the
@@ -163,6 +164,13 @@ int mc_xc_rows_forward_stats(const float* src, const int64_t* job_off, int64_t r
                              int njobs, const mc_xc_geom* geom, int hl, int hu, int wl, int wu,
                              double* acc, float* fix, float* out3, const int* row_chord,
                              void* stream);
+/* The same reading the frames in their storage type (MC_STORE_F32 / MC_STORE_F16; job_off and row_stride
+ * in samples): fp16 frames are read as they are by the wavefront-per-row kernel (4096-column frames;
+ * MC_ERR_UNSUPPORTED otherwise: widen the stack and call mc_xc_rows_forward_stats). */
+int mc_xc_rows_forward_stats_t(const void* src, int storage, const int64_t* job_off, int64_t row_stride,
+                               const float* mask, const float* m0, void* T1, const void* tw_row,
+                               int njobs, const mc_xc_geom* q, int hl, int hu, int wl, int wu,
+                               double* acc, float* fix, float* out3, const int* row_chord, void* stream);
 
 /* K2.  Column FFT of T1, kept ky rows, times filt (or NULL) -> S[j][kx][kyi].
  * estimate_motion_xc.py:78,98 / :340-346. */
@@ -298,6 +306,12 @@ int mc_warp_rigid(const float* frames, int nframes, int h, int w, const float* s
  * phase 0 = mc_warp_rigid. */
 int mc_warp_rigid_phase(const float* frames, int nframes, int h, int w, const float* shifts_px,
                         float* scratch, float* out_frames, float* out_sum, int phase, void* stream);
+/* The same with the frames in their storage type (MC_STORE_F32 / MC_STORE_F16; outputs stay fp32): fp16
+ * frames are DMA'd to LDS as they are and widened on the way to the registers (half the read bytes).
+ * fp16 needs w % 8 == 0 and 16-byte aligned frames / out_frames, else MC_ERR_UNSUPPORTED (widen and
+ * call mc_warp_rigid). */
+int mc_warp_rigid_phase_t(const void* frames, int storage, int nframes, int h, int w, const float* shifts_px,
+                          float* scratch, float* out_frames, float* out_sum, int phase, void* stream);
 
 /* get_pixel_shifts (correct_motion.py:132-185) for one (2,GH,GW) lattice: out (h,w,2)
  * shifts in px.  scratch: mc_warp_scratch_bytes(1,h,w,GH,GW). */

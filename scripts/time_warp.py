@@ -6,6 +6,8 @@ dev = torch.device("cuda:0")
 t, h, w = 40, int(os.environ.get("HH","4096")), int(os.environ.get("WW","4096"))
 g = torch.Generator(device=dev).manual_seed(0)
 stack = torch.randn(t, h, w, generator=g, device=dev)
+if os.environ.get("HALF", "0") == "1":  # fp16 storage: the rigid kernel reads the 16-bit samples (6 B/px/frame)
+    stack = stack.half()
 sx = float(os.environ.get("SX", "nan"))
 sh = torch.stack([torch.round(torch.linspace(-6, 8, t)), torch.round(torch.linspace(5, -4, t)) if sx != sx else torch.full((t,), sx)], 1)
 field = mc.image_shifts_to_deformation_field(sh.to(dev), 1.0).contiguous()

@@ -264,6 +264,36 @@ def test_correct_rigid_field_fast_kernel(mc, dev, ps):
         assert float(d.max()) <= REL * float(ref.sum(0).abs().max())
 
 
+@pytest.mark.parametrize("shape", [(6, 256, 512), (3, 300, 1024), (2, 512, 1032), (4, 96, 264), (2, 128, 260),
+                                   (3, 1024, 4096)])
+def test_rigid_warp_reads_fp16_frames_natively(mc, dev, shape):
+    """An fp16 stack through the rigid kernel (mc_warp_rigid_phase_t, MC_STORE_F16: the window is DMA'd
+    as raw 16-bit samples and widened between LDS and the registers) gives EXACTLY the frames and the
+    sum of its fp32 up-cast through the fp32 kernel (the conversion is exact, the arithmetic the same):
+    integer and fractional shifts of both signs, shifts larger than the tile margins, tiles cut by
+    every border, odd and even window start columns, a width that is not a multiple of 8 (fallback)."""
+    from torch_motion_correction_amd import engine
+
+    t, h, w = shape
+    g = torch.Generator().manual_seed(h * 7 + w)
+    st16 = (torch.randn(t, h, w, generator=g) * 3 + 1).half().to(dev)
+    for fld in (torch.randn(2, t, 1, 1, generator=g) * 6,
+                torch.round(torch.randn(2, t, 1, 1, generator=g) * 9),
+                torch.tensor([[40.5] * t, [-77.25] * t])[:, :, None, None]):
+        total16, frames16 = mc.motion_correct_sum(st16, fld.to(dev), 1.0, return_frames=True)
+        total32, frames32 = mc.motion_correct_sum(st16.float(), fld.to(dev), 1.0, return_frames=True)
+        assert torch.equal(frames16, frames32)
+        assert torch.equal(total16, total32)
+        assert torch.equal(mc.correct_motion(st16, fld.to(dev), 1.3), mc.correct_motion(st16.float(), fld.to(dev), 1.3))
+        assert torch.equal(mc.motion_correct_sum(st16, fld.to(dev), 1.0), total32)
+    # and against the oracle on the up-cast (SURVEY Q11: the reference itself cannot run fp16)
+    fld = torch.randn(2, t, 1, 1, generator=g) * 4
+    if h * w <= 512 * 1032:
+        ref = oracle.correct_motion(st16.float().cpu(), fld, 1.0)
+        knife = knife_edge_mask(st16.float().cpu(), fld, 1.0, "catmull_rom", eps=2e-3)
+        assert_frames_close(mc.correct_motion(st16, fld.to(dev), 1.0), ref, knife)
+
+
 def test_rigid_and_general_kernels_agree(mc, dev):
     """The rigid kernel is a specialisation: same field through both kernels."""
     from torch_motion_correction_amd import api
@@ -416,6 +446,32 @@ def test_full_size_known_drift(mc, big_stack):
     f = mc.estimate_global_motion(stack, 1.0).cpu()
     assert f[0, :, 0, 0].tolist() == [float(d - dy[20]) for d in dy]
     assert f[1, :, 0, 0].tolist() == [float(d - dx[20]) for d in dx]
+
+
+def test_full_size_fp16_storage_is_read_natively(mc, big_stack, dev):
+    """BASELINE C2's stack stored as fp16 (N2): K1 and the rigid warp read the 16-bit samples as they are
+    (mc_xc_rows_forward_stats_t, mc_warp_rigid_phase_t).  The conversion is exact and the arithmetic the
+    same, so every output EQUALS that of the up-cast stack through the fp32 kernels: shifts (= the known
+    drift), normalisation statistics, frames, sum; the movie pipeline takes fp16 movies too."""
+    from torch_motion_correction_amd import engine, pipeline
+
+    stack, dy, dx = big_stack
+    st16 = stack[:12].half()
+    up = st16.float()
+    f16 = mc.estimate_global_motion(st16, 1.0)
+    f32 = mc.estimate_global_motion(up, 1.0)
+    assert torch.equal(f16, f32)
+    assert f16[0, :, 0, 0].tolist() == [float(d - dy[6]) for d in dy[:12]]
+    assert f16[1, :, 0, 0].tolist() == [float(d - dx[6]) for d in dx[:12]]
+    # the filtered, normalised spectra themselves (fused statistics included)
+    pl = engine.planmod.get_xc_plan(4096, 4096, 1.0, 500.0, (300, 10), dev)
+    assert torch.equal(engine._global_spectra(st16, pl), engine._global_spectra(up, pl))
+    t16, fr16 = mc.motion_correct_sum(st16, f16, 1.0, return_frames=True)
+    t32, fr32 = mc.motion_correct_sum(up, f32, 1.0, return_frames=True)
+    assert torch.equal(fr16, fr32) and torch.equal(t16, t32)
+    res = pipeline.motion_correct_movies([st16, up], 1.0, device=dev)
+    assert torch.equal(res[0].field, res[1].field) and torch.equal(res[0].total, res[1].total)
+    assert res[0].field.cpu()[0, :, 0, 0].tolist() == [float(d - dy[6]) for d in dy[:12]]
 
 
 def test_full_size_warp_properties(mc, big_stack, dev):

@@ -52,6 +52,7 @@ SIGNATURES = {
     "mc_xc_rows_forward_dual": [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, GP, vp, vp],
     "mc_xc_rows_forward_dual_t": [vp, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, GP, vp, vp],
     "mc_xc_rows_forward_stats": [vp, vp, i64, vp, vp, vp, vp, i32, GP, i32, i32, i32, i32, vp, vp, vp, vp, vp],
+    "mc_xc_rows_forward_stats_t": [vp, i32, vp, i64, vp, vp, vp, vp, i32, GP, i32, i32, i32, i32, vp, vp, vp, vp, vp],
     "mc_xc_cols_forward": [vp, vp, vp, vp, i32, GP, vp],
     "mc_xc_cols_forward_fix": [vp, vp, vp, vp, i32, GP, vp, vp, vp],
     "mc_xc_cols_inverse": [vp, vp, vp, vp, vp, vp, f32, i32, GP, vp],
@@ -59,6 +60,7 @@ SIGNATURES = {
     "mc_xc_near_rows": [GP],
     "mc_xc_correlate_argmax": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, f32, i32, GP, vp],
     "mc_xc_provisional_mean": [vp, i32, vp, vp],
+    "mc_xc_provisional_mean_t": [vp, i32, i32, vp, vp],
     "mc_xc_peak_neighbourhood": [vp, vp, vp, vp, i32, GP, vp],
     "mc_xc_ref_mean_except_current": [vp, vp, vp, vp, vp, vp, i32, i32, i64, f32, vp],
     "mc_field_accumulate": [vp, vp, vp, i32, i32, i32, i32, f32, f32, i32, vp, vp],
@@ -70,6 +72,7 @@ SIGNATURES = {
     "mc_warp_rigid_scratch_bytes": [i32, i32, i32, C.POINTER(C.c_int64)],
     "mc_warp_rigid": [vp, i32, i32, i32, vp, vp, vp, vp, vp],
     "mc_warp_rigid_phase": [vp, i32, i32, i32, vp, vp, vp, vp, i32, vp],
+    "mc_warp_rigid_phase_t": [vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp],
     "mc_pixel_shifts": [vp, i32, i32, i32, i32, f32, vp, vp, vp],
     "mc_pixel_shifts_at": [vp, i32, i32, i32, i32, f32, vp, i64, vp, vp],
     "mc_full_spectrum_pitch": [i32],

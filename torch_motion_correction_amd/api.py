@@ -128,7 +128,7 @@ def estimate_global_motion(image, pixel_spacing, reference_frame=None, b_factor=
     pixel_spacing; the reference frame's entry is exactly 0)."""
     out_dev = _out_device(image, device)
     dev = require_gpu(out_dev)
-    img = _stage(image, dev)
+    img = _stage(image, dev, keep_half=True)  # fp16 stacks: K1 reads the 16-bit samples (4096-column frames)
     t = img.shape[0]
     ref = t // 2 if reference_frame is None else reference_frame
     normalize_frame_index(ref, t)  # IndexError outside [-t, t), as filtered_fft[ref] (xc.py:101)

@@ -628,6 +628,18 @@ __global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES, RIGID_MINW) void warp_rig
 #define RD_QUADS_PAD (((RIGID_NQ + 63) / 64) * 64)  // DMA granule: 64 lanes x 16 B
 typedef __attribute__((address_space(3))) void* lds_vptr;
 
+// a0 b0 + a1 b1 + ... + a4 b4 as one product and four fused multiply-adds in this order: the fp32 and
+// the fp16 strip bodies then round identically (left to the contraction pass the two bodies fused
+// different products and differed in the last bit for 5 % of the pixels)
+__device__ __forceinline__ float rigid_dot5(float a0, float b0, float a1, float b1, float a2, float b2, float a3,
+                                            float b3, float a4, float b4) {
+  float r = a0 * b0;
+  r = __builtin_fmaf(a1, b1, r);
+  r = __builtin_fmaf(a2, b2, r);
+  r = __builtin_fmaf(a3, b3, r);
+  return __builtin_fmaf(a4, b4, r);
+}
+
 template <bool WRITE_FRAMES, bool WRITE_SUM, bool FULL, int QUADS>
 __device__ __forceinline__ void rigid_strip_dma(const RigidArgs& a, const float4* wrow, int f,
                                                 int y0, int x0, float wyv,
@@ -649,8 +661,7 @@ __device__ __forceinline__ void rigid_strip_dma(const RigidArgs& a, const float4
     float* Hn = H[rr % 5];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      Hn[k] = (((wx[0][k] * e[k] + wx[1][k] * e[k + 1]) + wx[2][k] * e[k + 2]) +
-               wx[3][k] * e[k + 3]) + wx[4][k] * e[k + 4];
+      Hn[k] = rigid_dot5(wx[0][k], e[k], wx[1][k], e[k + 1], wx[2][k], e[k + 2], wx[3][k], e[k + 3], wx[4][k], e[k + 4]);
     if (rr >= 4) {
       const int ro = rr - 4;
       float wy[5];
@@ -660,9 +671,8 @@ __device__ __forceinline__ void rigid_strip_dma(const RigidArgs& a, const float4
       float o[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        o[k] = (((wy[0] * H[(ro + 0) % 5][k] + wy[1] * H[(ro + 1) % 5][k]) +
-                 wy[2] * H[(ro + 2) % 5][k]) + wy[3] * H[(ro + 3) % 5][k]) +
-               wy[4] * H[(ro + 4) % 5][k];
+        o[k] = rigid_dot5(wy[0], H[(ro + 0) % 5][k], wy[1], H[(ro + 1) % 5][k], wy[2], H[(ro + 2) % 5][k], wy[3],
+                          H[(ro + 3) % 5][k], wy[4], H[(ro + 4) % 5][k]);
       if (FULL || (y0 + ro < h && x0 < w)) {
         if (WRITE_FRAMES) *reinterpret_cast<float4*>(orow + (int64_t)ro * w) = make_float4(o[0], o[1], o[2], o[3]);
         if (WRITE_SUM) {
@@ -818,6 +828,197 @@ void warp_rigid_dma(RigidArgs a) {
       if (yo < h) {
         // one block owns its tile's sum over all frames: a plain store (no zero fill, no read-back);
         // w % 4 == 0 on this path, so the quad is 16-byte aligned whenever out_sum is
+        float* dst = a.out_sum + (int64_t)yo * w + x0;
+        if ((((uintptr_t)a.out_sum) & 15) == 0) {
+          *reinterpret_cast<float4*>(dst) = make_float4(acc[ro][0], acc[ro][1], acc[ro][2], acc[ro][3]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) dst[k] = acc[ro][k];
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ rigid warp, LDS-DMA, fp16 frames
+// The same kernel for frames stored as fp16 (N2: fp16 storage read natively): the window goes
+// HBM -> LDS as the raw 16-bit samples -- half the bytes of the fp32 kernel on the read side -- and is
+// widened on the way from LDS to the registers (8 v_cvt_f32_f16 per window row of a lane).  The
+// global side of the DMA needs 4-byte alignment, so the window starts at the EVEN column at or left
+// of x_tile + Sx - 1; the parity p of that column is wave-uniform per frame and selects one of two
+// strip bodies with compile-time sample positions: a lane's 8-sample window is the halfs
+// [4 L + p, 4 L + p + 8) of the tile row = two (p = 0) or three (p = 1) aligned ds_read_b64.
+// Tile rows hold QH = 32 WX + 1 units of 8 samples.  Requires w % 8 == 0 and 16-byte aligned frames.
+__device__ __forceinline__ float rh_lo(unsigned v) {
+  return (float)__builtin_bit_cast(_Float16, (unsigned short)(v & 0xffffu));
+}
+__device__ __forceinline__ float rh_hi(unsigned v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(v >> 16)); }
+
+template <bool WRITE_FRAMES, bool WRITE_SUM, bool FULL, int P, int UNITS8>
+__device__ __forceinline__ void rigid_strip_half(const RigidArgs& a, const uint2* wrow, int f, int y0, int x0,
+                                                 float wyv, const float (&wx)[5][4],
+                                                 float (&acc)[RIGID_ROWS][4]) {
+  const int h = a.h, w = a.w;
+  float* orow = WRITE_FRAMES ? a.out_frames + (int64_t)f * h * w + (int64_t)y0 * w + x0 : nullptr;
+  float H[5][4];
+#pragma unroll
+  for (int rr = 0; rr < RIGID_ROWS + 4; ++rr) {
+    if (RIGID_SB > 0 && (rr % (RIGID_SB > 0 ? RIGID_SB : 1)) == 0) __builtin_amdgcn_sched_barrier(0);
+    const uint2 u0 = wrow[rr * UNITS8], u1 = wrow[rr * UNITS8 + 1];
+    float e[8];
+    if constexpr (P == 0) {
+      e[0] = rh_lo(u0.x); e[1] = rh_hi(u0.x); e[2] = rh_lo(u0.y); e[3] = rh_hi(u0.y);
+      e[4] = rh_lo(u1.x); e[5] = rh_hi(u1.x); e[6] = rh_lo(u1.y); e[7] = rh_hi(u1.y);
+    } else {
+      const unsigned u2x = reinterpret_cast<const unsigned*>(wrow + rr * UNITS8 + 2)[0];
+      e[0] = rh_hi(u0.x); e[1] = rh_lo(u0.y); e[2] = rh_hi(u0.y); e[3] = rh_lo(u1.x);
+      e[4] = rh_hi(u1.x); e[5] = rh_lo(u1.y); e[6] = rh_hi(u1.y); e[7] = rh_lo(u2x);
+    }
+    float* Hn = H[rr % 5];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      Hn[k] = rigid_dot5(wx[0][k], e[k], wx[1][k], e[k + 1], wx[2][k], e[k + 2], wx[3][k], e[k + 3], wx[4][k], e[k + 4]);
+    if (rr >= 4) {
+      const int ro = rr - 4;
+      float wy[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+        wy[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wyv), ro * 5 + i));
+      float o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        o[k] = rigid_dot5(wy[0], H[(ro + 0) % 5][k], wy[1], H[(ro + 1) % 5][k], wy[2], H[(ro + 2) % 5][k], wy[3],
+                          H[(ro + 3) % 5][k], wy[4], H[(ro + 4) % 5][k]);
+      if (FULL || (y0 + ro < h && x0 < w)) {
+        if (WRITE_FRAMES) *reinterpret_cast<float4*>(orow + (int64_t)ro * w) = make_float4(o[0], o[1], o[2], o[3]);
+        if (WRITE_SUM) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[ro][k] += o[k];
+        }
+      }
+    }
+  }
+}
+
+template <bool WRITE_FRAMES, bool WRITE_SUM, int WX, int WY>
+__global__ __launch_bounds__(RIGID_LANES* WX* WY, 4)
+void warp_rigid_dma_h(RigidArgs a) {
+  constexpr int NWAVES = WX * WY;
+  constexpr int TROWS = WY * RIGID_ROWS + 4;   // input rows per tile
+  constexpr int QH = WX * 32 + 1;              // 16-byte units (8 samples) per tile row
+  constexpr int NQ = TROWS * QH;
+  constexpr int UNITS_PAD = ((NQ + 63) / 64) * 64;  // DMA granule: 64 lanes x 16 B
+  extern __shared__ __attribute__((aligned(16))) char smem_rd[];
+  float4* const b0 = reinterpret_cast<float4*>(smem_rd);
+  const _Float16* const frames = reinterpret_cast<const _Float16*>(a.frames);
+  const int nt = a.tiles_x * a.tiles_y;
+  const int b = blockIdx.x;
+  int tile = b;
+  if ((nt & 7) == 0) tile = (b & 7) * (nt >> 3) + (b >> 3);  // one band of tile rows per XCD
+  const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
+  const int h = a.h, w = a.w;
+  const int lane = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int wvx = wave % WX, wvy = wave / WX;
+  const int tid = wave * RIGID_LANES + lane;
+  const int xt = txi * (RIGID_LANES * 4 * WX);
+  const int yt = tyi * (WY * RIGID_ROWS);
+  const int x0 = xt + wvx * (RIGID_LANES * 4) + lane * 4;
+  const int y0 = yt + wvy * RIGID_ROWS;
+  const int64_t hw = (int64_t)h * w;
+  float acc[RIGID_ROWS][4];
+#pragma unroll
+  for (int r = 0; r < RIGID_ROWS; ++r)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[r][k] = 0.f;
+  const bool full_tile = yt + WY * RIGID_ROWS <= h && xt + RIGID_LANES * 4 * WX <= w;
+  const int f_lo = a.frames_in_grid ? (int)blockIdx.y * a.frames_in_grid : 0;
+  const int f_hi = a.frames_in_grid ? min(f_lo + a.frames_in_grid, a.nframes) : a.nframes;
+
+  auto dma = [&](int f) {
+    const _Float16* fr = frames + (int64_t)f * hw;
+    const int Sy = a.S[2 * f], Sx = a.S[2 * f + 1];
+    const int axe = (xt + Sx - 1) & ~1;  // even column: 4-byte aligned on the global side
+    for (int i = wave; i < UNITS_PAD / 64; i += NWAVES) {
+      int q = i * 64 + lane;
+      q = q < NQ ? q : NQ - 1;  // tail lanes re-load the last unit into the pad
+      const int tr = q / QH, qc = q - tr * QH;
+      int r = yt + Sy - 1 + tr;
+      r = r < 0 ? 0 : (r > h - 1 ? h - 1 : r);
+      int c = axe + 8 * qc;
+      c = c < 0 ? 0 : (c > w - 8 ? w - 8 : c);  // whole units inside the row; clamped ones are patched
+      __builtin_amdgcn_global_load_lds(fr + (int64_t)r * w + c, (lds_vptr)(b0 + i * 64), 16, 0, 0);
+    }
+  };
+  // border padding for edge tiles: a unit whose 8 columns are not all inside the row was DMA'd from a
+  // clamped address; its samples are re-fetched one by one at their clipped column
+  auto patch = [&](int f) {
+    const int Sy = a.S[2 * f], Sx = a.S[2 * f + 1];
+    const int axe = (xt + Sx - 1) & ~1;
+    if (axe >= 0 && axe + 8 * QH <= w) return false;
+    const _Float16* fr = frames + (int64_t)f * hw;
+    _Float16* t = reinterpret_cast<_Float16*>(b0);
+    for (int q = tid; q < NQ; q += RIGID_LANES * NWAVES) {
+      const int tr = q / QH, qc = q - tr * QH;
+      const int s0 = axe + 8 * qc;
+      if (s0 >= 0 && s0 <= w - 8) continue;
+      int r = yt + Sy - 1 + tr;
+      r = r < 0 ? 0 : (r > h - 1 ? h - 1 : r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        int c = s0 + e;
+        c = c < 0 ? 0 : (c > w - 1 ? w - 1 : c);
+        t[8 * q + e] = fr[(int64_t)r * w + c];
+      }
+    }
+    return true;
+  };
+
+  float wx[5][4];
+  float wyv = 0.f;
+  auto load_weights = [&](int f) {
+    wyv = 0.f;
+    const int64_t idx = (int64_t)y0 * 5 + lane;
+    if (lane < 5 * RIGID_ROWS && idx < (int64_t)h * 5) wyv = a.Wy[(int64_t)f * 5 * h + idx];
+    const float* Wx = a.Wx + (int64_t)f * 5 * w + x0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (x0 < w) t = *reinterpret_cast<const float4*>(Wx + (int64_t)j * w);
+      wx[j][0] = t.x; wx[j][1] = t.y; wx[j][2] = t.z; wx[j][3] = t.w;
+    }
+  };
+  // this lane's first 8-byte unit (4 samples): row (wvy RIGID_ROWS), sample 4 (64 wvx + lane)
+  const uint2* const strip = reinterpret_cast<const uint2*>(b0) + (wvy * RIGID_ROWS) * (2 * QH) + wvx * RIGID_LANES + lane;
+
+  load_weights(f_lo);
+  dma(f_lo);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (patch(f_lo)) __syncthreads();
+  for (int f = f_lo; f < f_hi; ++f) {
+    const int par = __builtin_amdgcn_readfirstlane((xt + a.S[2 * f + 1] - 1) & 1);
+    if (par) {
+      if (full_tile) rigid_strip_half<WRITE_FRAMES, WRITE_SUM, true, 1, 2 * QH>(a, strip, f, y0, x0, wyv, wx, acc);
+      else rigid_strip_half<WRITE_FRAMES, WRITE_SUM, false, 1, 2 * QH>(a, strip, f, y0, x0, wyv, wx, acc);
+    } else {
+      if (full_tile) rigid_strip_half<WRITE_FRAMES, WRITE_SUM, true, 0, 2 * QH>(a, strip, f, y0, x0, wyv, wx, acc);
+      else rigid_strip_half<WRITE_FRAMES, WRITE_SUM, false, 0, 2 * QH>(a, strip, f, y0, x0, wyv, wx, acc);
+    }
+    if (f + 1 < f_hi) {
+      __syncthreads();  // everyone must be done reading before the tile is refilled
+      dma(f + 1);
+      load_weights(f + 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (patch(f + 1)) __syncthreads();
+    }
+  }
+  if (WRITE_SUM && x0 < w) {
+#pragma unroll
+    for (int ro = 0; ro < RIGID_ROWS; ++ro) {
+      const int yo = y0 + ro;
+      if (yo < h) {
         float* dst = a.out_sum + (int64_t)yo * w + x0;
         if ((((uintptr_t)a.out_sum) & 15) == 0) {
           *reinterpret_cast<float4*>(dst) = make_float4(acc[ro][0], acc[ro][1], acc[ro][2], acc[ro][3]);
@@ -2133,8 +2334,27 @@ int mc_warp_rigid_scratch_bytes(int nframes, int h, int w, int64_t* bytes) {
 
 // phase 0: weight tables + resampling (mc_warp_rigid); 1: tables only; 2: resampling only, the
 // tables of an earlier phase-1 call with the same arguments are in `scratch`
+static int warp_rigid_impl(const void* frames_any, int storage, int nframes, int h, int w, const float* shifts_px,
+                           float* scratch, float* out_frames, float* out_sum, int phase, void* stream);
+
 int mc_warp_rigid_phase(const float* frames, int nframes, int h, int w, const float* shifts_px,
                         float* scratch, float* out_frames, float* out_sum, int phase, void* stream) {
+  return warp_rigid_impl(frames, MC_STORE_F32, nframes, h, w, shifts_px, scratch, out_frames, out_sum, phase, stream);
+}
+
+int mc_warp_rigid_phase_t(const void* frames, int storage, int nframes, int h, int w, const float* shifts_px,
+                          float* scratch, float* out_frames, float* out_sum, int phase, void* stream) {
+  return warp_rigid_impl(frames, storage, nframes, h, w, shifts_px, scratch, out_frames, out_sum, phase, stream);
+}
+
+static int warp_rigid_impl(const void* frames_any, int storage, int nframes, int h, int w, const float* shifts_px,
+                           float* scratch, float* out_frames, float* out_sum, int phase, void* stream) {
+  const float* frames = static_cast<const float*>(frames_any);
+  if (storage != MC_STORE_F32 && storage != MC_STORE_F16) return MC_ERR_UNSUPPORTED;
+  // fp16 frames: only the LDS-DMA kernel's 512 x 32 geometry, rows of whole 8-sample units
+  if (storage == MC_STORE_F16 && ((w % 8) != 0 || (((uintptr_t)frames_any) & 15) ||
+                                  (out_frames && (((uintptr_t)out_frames) & 15))))
+    return MC_ERR_UNSUPPORTED;
   if (!frames || !shifts_px || !scratch || (!out_frames && !out_sum)) return MC_ERR_ARG;
   if (nframes < 1 || h < 2 || w < 2 || (((uintptr_t)scratch) & 15) || phase < 0 || phase > 2) return MC_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -2177,6 +2397,25 @@ int mc_warp_rigid_phase(const float* frames, int nframes, int h, int w, const fl
   a.frames_in_grid = out_sum ? 0 : 1;
   dim3 grid(a.tiles_x * a.tiles_y, a.frames_in_grid ? (nframes + a.frames_in_grid - 1) / a.frames_in_grid : 1),
       block(RIGID_LANES, WX * WY);
+  if (storage == MC_STORE_F16) {
+    constexpr int HX = 2, HY = 4;  // 512 x 32 tiles
+    a.tiles_x = (w + RIGID_LANES * 4 * HX - 1) / (RIGID_LANES * 4 * HX);
+    a.tiles_y = (h + HY * RIGID_ROWS - 1) / (HY * RIGID_ROWS);
+    dim3 gridh(a.tiles_x * a.tiles_y, a.frames_in_grid ? (nframes + a.frames_in_grid - 1) / a.frames_in_grid : 1),
+        blockh(RIGID_LANES, HX * HY);
+    const size_t ldsh = (size_t)((((HY * RIGID_ROWS + 4) * (HX * 32 + 1)) + 63) / 64) * 64 * 16;
+#define MC_RDH_GO(F, S)                                                                              \
+  do {                                                                                               \
+    auto k = warp_rigid_dma_h<F, S, HX, HY>;                                                          \
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh); \
+    hipLaunchKernelGGL(k, gridh, blockh, ldsh, s, a);                                                \
+  } while (0)
+    if (out_frames && out_sum) MC_RDH_GO(true, true);
+    else if (out_frames) MC_RDH_GO(true, false);
+    else MC_RDH_GO(false, true);
+#undef MC_RDH_GO
+    return mc_check_launch();
+  }
   if (dma_ok) {
 #define MC_RD_GO(F, S, NB, GX, GY)                                                                  \
   do {                                                                                              \

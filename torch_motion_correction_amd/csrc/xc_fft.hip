@@ -202,9 +202,25 @@ __device__ __forceinline__ void wf_pin(int& v, float dep) { asm volatile("" : "+
 // N1LO and N1HI - 1 lie wholly inside the support (host checks) and load unclamped.
 // Statistics: box.wl / box.wu are multiples of 256 (host checks), so a chunk is inside
 // the box or outside it as a whole.
-template <int N1LO, int N1HI, bool CLAMP_ALL>
-__device__ __forceinline__ void wf_load_px(const float* __restrict__ row, int t, int xlo, int xhi,
+template <int N1LO, int N1HI, bool CLAMP_ALL, bool HALF = false>
+__device__ __forceinline__ void wf_load_px(const void* __restrict__ row_any, int t, int xlo, int xhi,
                                            float4 (&px)[16]) {
+  if constexpr (HALF) {
+    // fp16 storage: the lane's four samples are 8 bytes; they stay RAW in px[n1].x / .y (converting here
+    // would make the prefetch wait for its own loads) and are widened where the row is consumed
+    const _Float16* row = static_cast<const _Float16*>(row_any);
+#pragma unroll
+    for (int n1 = N1LO; n1 < N1HI; ++n1) {
+      const int x = 256 * n1 + 4 * t;
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      const int xs = (CLAMP_ALL || n1 == N1LO || n1 == N1HI - 1) ? min(max(x, xlo), xhi) : x;
+      const f2 q = __builtin_nontemporal_load(reinterpret_cast<const f2*>(row + xs));
+      px[n1].x = q.x;
+      px[n1].y = q.y;
+    }
+    return;
+  }
+  const float* row = static_cast<const float*>(row_any);
   // Branch-free: a lane whose quad lies outside [xlo, xhi + 4) -- the support box, or with
   // CLAMP_ALL and a chord table this row's own chord of the mask disk -- reads the nearest quad
   // inside it instead (a line its neighbours fetch anyway: no extra HBM traffic); the value
@@ -231,17 +247,24 @@ __device__ __forceinline__ void wf_load_mask(const float* __restrict__ mrow, int
 // and the next row's on exit (loaded right after the current ones were consumed, so the
 // HBM latency of row i+1 hides behind the transform of row i); 2: the same for mk too.
 // next_row / next_mrow are null after the last row (wave-uniform).
-template <int KEEP, bool STATS, int N1LO, int N1HI, bool CLAMP_ALL, int PREFETCH>
+// raw bits of two fp16 samples -> two floats
+__device__ __forceinline__ wf2 wf_unpack_h2(float bits) {
+  const unsigned v = __float_as_uint(bits);
+  return wf2{(float)__builtin_bit_cast(_Float16, (unsigned short)(v & 0xffffu)),
+             (float)__builtin_bit_cast(_Float16, (unsigned short)(v >> 16))};
+}
+
+template <int KEEP, bool STATS, int N1LO, int N1HI, bool CLAMP_ALL, int PREFETCH, bool HALF = false>
 __device__ __forceinline__ void wf_row(float4 (&px)[16], float4 (&mk)[16],
-                                       const float* __restrict__ row, const float* __restrict__ mrow,
-                                       const float* __restrict__ next_row,
+                                       const void* __restrict__ row, const float* __restrict__ mrow,
+                                       const void* __restrict__ next_row,
                                        const float* __restrict__ next_mrow, int t, wf2* slab,
                                        const cfloat* twA, const cfloat* twB, const cfloat* twK,
                                        const XcGeom& g, int box_lo, int box_hi, float mean, float rstd,
                                        float& st_s, float& st_q, wf2 (&X)[4][KEEP], int xlo, int xhi,
                                        int nxlo, int nxhi) {
   wf2 A0[16], A1[16];
-  if (PREFETCH < 1) wf_load_px<N1LO, N1HI, CLAMP_ALL>(row, t, xlo, xhi, px);
+  if (PREFETCH < 1) wf_load_px<N1LO, N1HI, CLAMP_ALL, HALF>(row, t, xlo, xhi, px);
   if (PREFETCH < 2) wf_load_mask<N1LO, N1HI>(mrow, t, mk);
   auto condition = [&](auto in_box) {
     constexpr bool INBOX = decltype(in_box)::value;
@@ -249,7 +272,8 @@ __device__ __forceinline__ void wf_row(float4 (&px)[16], float4 (&mk)[16],
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {
       if (n1 >= N1LO && n1 < N1HI) {
-        const wf2 a01 = wf2{px[n1].x, px[n1].y} - mean, a23 = wf2{px[n1].z, px[n1].w} - mean;
+        const wf2 a01 = (HALF ? wf_unpack_h2(px[n1].x) : wf2{px[n1].x, px[n1].y}) - mean;
+        const wf2 a23 = (HALF ? wf_unpack_h2(px[n1].y) : wf2{px[n1].z, px[n1].w}) - mean;
         if (INBOX) {  // chunk weight 1 inside the box, 0 outside (scalar): no branch per chunk
           const float cw = (n1 >= box_lo && n1 < box_hi) ? 1.f : 0.f;
           const wf2 sa = a01 + a23;
@@ -278,7 +302,7 @@ __device__ __forceinline__ void wf_row(float4 (&px)[16], float4 (&mk)[16],
     if (next_row) {  // issued once this row's samples have been consumed, not earlier
       int tp = t;
       wf_pin(tp, A1[N1HI - 1].y);
-      wf_load_px<N1LO, N1HI, CLAMP_ALL>(next_row, tp, nxlo, nxhi, px);
+      wf_load_px<N1LO, N1HI, CLAMP_ALL, HALF>(next_row, tp, nxlo, nxhi, px);
       if (PREFETCH >= 2) wf_load_mask<N1LO, N1HI>(next_mrow, tp, mk);
     }
   }
@@ -351,9 +375,9 @@ __device__ __forceinline__ void wf_row(float4 (&px)[16], float4 (&mk)[16],
   wf_unpack_lane<KEEP>(z, wk, L.self != 0, X);
 }
 
-template <int KEEP, bool STATS, int N1LO, int N1HI, bool CLAMP_ALL, int WF_PREFETCH>
+template <int KEEP, bool STATS, int N1LO, int N1HI, bool CLAMP_ALL, int WF_PREFETCH, bool HALF = false>
 __global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
-    const float* __restrict__ src, const int64_t* __restrict__ job_off, int64_t row_stride,
+    const void* __restrict__ src, const int64_t* __restrict__ job_off, int64_t row_stride,
     const float* __restrict__ mask, const float* __restrict__ mean_rstd, cfloat* __restrict__ T1,
     const cfloat* __restrict__ tw_row, XcGeom g, XcBox box, double* __restrict__ stats_acc,
     const int2* __restrict__ chord, int lines16) {
@@ -402,7 +426,9 @@ __global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
   }
   const float mean = mean_rstd ? mean_rstd[0] : 0.f;
   const float rstd = mean_rstd ? mean_rstd[1] : 1.f;
-  const float* base = src + job_off[job];
+  // frames in their storage type: fp32, or (HALF) fp16 read as it is; job_off / row_stride in samples
+  const char* base = static_cast<const char*>(src) + job_off[job] * (HALF ? 2 : 4);
+  auto row_at = [&](int y) -> const void* { return base + (int64_t)y * row_stride * (HALF ? 2 : 4); };
   float st_s = 0.f, st_q = 0.f;
   cfloat* out = T1 + (int64_t)job * g.nkx * g.ny;
   // A workgroup takes 16 rows in two rounds of 8 consecutive rows; in a round wave wv
@@ -419,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
   auto bounds = [&](int y) { return (CLAMP_ALL && chord) ? chord[y] : make_int2(bxlo, bxhi); };
   if (WF_PREFETCH >= 1 && nrows > 0) {
     const int2 c0 = bounds(g.y0 + row_of(0));
-    wf_load_px<N1LO, N1HI, CLAMP_ALL>(base + (int64_t)(g.y0 + row_of(0)) * row_stride, t, c0.x, c0.y, px);
+    wf_load_px<N1LO, N1HI, CLAMP_ALL, HALF>(row_at(g.y0 + row_of(0)), t, c0.x, c0.y, px);
   }
   if (WF_PREFETCH >= 2 && nrows > 0)
     wf_load_mask<N1LO, N1HI>(mask + (int64_t)(g.y0 + row_of(0)) * g.W, t, mk);
@@ -428,15 +454,15 @@ __global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
 #pragma unroll 1
   for (int rr = 0; rr < nrows; ++rr) {
     const int y = g.y0 + row_of(rr);
-    const float* row = base + (int64_t)y * row_stride;
+    const void* row = row_at(y);
     const float* mrow = mask + (int64_t)y * g.W;
     const int yn = g.y0 + row_of(rr + 1);
-    const float* next_row = rr + 1 < nrows ? base + (int64_t)yn * row_stride : nullptr;
+    const void* next_row = rr + 1 < nrows ? row_at(yn) : nullptr;
     const float* next_mrow = mask + (int64_t)yn * g.W;
     const bool in_box_row = STATS && y >= box.hl && y < box.hu;
     wf2 X[4][KEEP];
     const int2 cb = bounds(y), cn = bounds(rr + 1 < nrows ? yn : y);
-    wf_row<KEEP, STATS, N1LO, N1HI, CLAMP_ALL, WF_PREFETCH>(px, mk, row, mrow, next_row, next_mrow, t,
+    wf_row<KEEP, STATS, N1LO, N1HI, CLAMP_ALL, WF_PREFETCH, HALF>(px, mk, row, mrow, next_row, next_mrow, t,
                                                             slab, twA, twB, twK, g, box.wl >> 8,
                                                             in_box_row ? (box.wu >> 8) : 0, mean, rstd,
                                                             st_s, st_q, X, cb.x, cb.y, cn.x, cn.y);
@@ -693,10 +719,11 @@ __global__ __launch_bounds__(256) void xc_rows_fwd_wave512(
 
 // Provisional mean of the fused-statistics path: m0 = {mean of n samples, 1, 1} by ONE
 // workgroup (any value near the true mean keeps the linear fix-up free of cancellation).
-__global__ __launch_bounds__(256) void xc_provisional_mean_kernel(const float* __restrict__ x, int n,
+template <typename T>
+__global__ __launch_bounds__(256) void xc_provisional_mean_kernel(const T* __restrict__ x, int n,
                                                                   float* __restrict__ m0) {
   double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) s += (double)x[i];
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)(float)x[i];
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
   __shared__ double part[4];
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
@@ -1536,11 +1563,17 @@ static int rows_forward_impl(const float* src, const int64_t* job_off, int64_t r
                              const int* job_expo, const float* mask, const float* mean_rstd,
                              void* T1, const void* tw_row, int njobs, const mc_xc_geom* q,
                              const XcBox* box, double* stats_acc, void* stream,
-                             const int* row_chord = nullptr) {
+                             const int* row_chord = nullptr, bool half = false) {
   XcGeom g;
   int rc = geom_from(q, &g, true, false);
   if (rc) return rc;
   if (!src || !job_off || !T1 || !tw_row || njobs < 1) return MC_ERR_ARG;
+  // fp16 samples: only the wave-per-row engine reads them (4096-column frames); anything else is
+  // MC_ERR_UNSUPPORTED and the caller widens the stack once
+  if (half && !(g.W == 2 * WF_N && g.nkx <= 512 && (g.ny % 8) == 0 && mask && !job_expo &&
+                wave_rows_aligned(src, mask, row_stride) &&
+                (!stats_acc || (((box ? box->wl : 0) | (box ? box->wu : 0)) & 255) == 0)))
+    return MC_ERR_UNSUPPORTED;
   const int logn = mc_ilog2(g.W) - 1;
   XcBox b = box ? *box : XcBox{0, 0, 0, 0};
   if (g.W == 2 * WF_N && g.nkx <= 512 && (g.ny % 8) == 0 && mask && !job_expo &&
@@ -1566,6 +1599,22 @@ static int rows_forward_impl(const float* src, const int64_t* job_off, int64_t r
                        mean_rstd, (cfloat*)T1, (const cfloat*)tw_row, g, b, stats_acc,             \
                        (const int2*)row_chord, lines16);                                           \
   } while (0)
+#define MC_WAVE_LAUNCH_H(KEEP, ST)                                                                \
+  do {                                                                                            \
+    auto kw = xc_rows_fwd_wave<KEEP, ST, 0, 16, true, WF_PREFETCH_DEFAULT, true>;                 \
+    if (dyn) (void)hipFuncSetAttribute((const void*)kw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
+    hipLaunchKernelGGL(kw, grid, dim3(256), dyn, (hipStream_t)stream, (const void*)src, job_off, row_stride, mask, \
+                       mean_rstd, (cfloat*)T1, (const cfloat*)tw_row, g, b, stats_acc,             \
+                       (const int2*)row_chord, lines16);                                           \
+  } while (0)
+    if (half) {  // fp16 storage: the general variant (all 16 chunks, per-row chord clamp when given)
+      if (g.nkx <= 256) {
+        if (stats_acc) MC_WAVE_LAUNCH_H(1, true); else MC_WAVE_LAUNCH_H(1, false);
+      } else {
+        if (stats_acc) MC_WAVE_LAUNCH_H(2, true); else MC_WAVE_LAUNCH_H(2, false);
+      }
+      return mc_check_launch();
+    }
 #define MC_WAVE_PICK(KEEP, ST)                                                              \
   do {                                                                                      \
     if (g.x0 >= 256 && g.x0 <= 512 && g.x1 >= 3584 && g.x1 <= 3840 && row_chord)            \
@@ -1644,7 +1693,16 @@ int mc_xc_rows_forward(const float* src, const int64_t* job_off, int64_t row_str
 
 int mc_xc_provisional_mean(const float* x, int n, float* m0, void* stream) {
   if (!x || !m0 || n < 1) return MC_ERR_ARG;
-  hipLaunchKernelGGL(xc_provisional_mean_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n, m0);
+  hipLaunchKernelGGL(xc_provisional_mean_kernel<float>, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n, m0);
+  return mc_check_launch();
+}
+
+int mc_xc_provisional_mean_t(const void* x, int storage, int n, float* m0, void* stream) {
+  if (!x || !m0 || n < 1) return MC_ERR_ARG;
+  if (storage == MC_STORE_F32) return mc_xc_provisional_mean(static_cast<const float*>(x), n, m0, stream);
+  if (storage != MC_STORE_F16) return MC_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(xc_provisional_mean_kernel<_Float16>, dim3(1), dim3(256), 0, (hipStream_t)stream,
+                     static_cast<const _Float16*>(x), n, m0);
   return mc_check_launch();
 }
 
@@ -1652,6 +1710,17 @@ int mc_xc_rows_forward_stats(const float* src, const int64_t* job_off, int64_t r
                              const float* mask, const float* m0, void* T1, const void* tw_row,
                              int njobs, const mc_xc_geom* q, int hl, int hu, int wl, int wu,
                              double* acc, float* fix, float* out3, const int* row_chord, void* stream) {
+  return mc_xc_rows_forward_stats_t(src, MC_STORE_F32, job_off, row_stride, mask, m0, T1, tw_row, njobs, q, hl, hu,
+                                    wl, wu, acc, fix, out3, row_chord, stream);
+}
+
+int mc_xc_rows_forward_stats_t(const void* src_any, int storage, const int64_t* job_off, int64_t row_stride,
+                               const float* mask, const float* m0, void* T1, const void* tw_row,
+                               int njobs, const mc_xc_geom* q, int hl, int hu, int wl, int wu,
+                               double* acc, float* fix, float* out3, const int* row_chord, void* stream) {
+  if (storage != MC_STORE_F32 && storage != MC_STORE_F16) return MC_ERR_UNSUPPORTED;
+  const float* src = static_cast<const float*>(src_any);
+  const bool half = storage == MC_STORE_F16;
   if (!m0 || !acc || !fix || !out3 || !q) return MC_ERR_ARG;
   if (hl < q->y0 || hu > q->y0 + q->ny || wl < q->x0 || wu > q->x1 || (wl & 1) || (wu & 1) ||
       hl >= hu || wl >= wu)
@@ -1660,7 +1729,7 @@ int mc_xc_rows_forward_stats(const float* src, const int64_t* job_off, int64_t r
   if (e != hipSuccess) return (int)e;
   XcBox box{hl, hu, wl, wu};
   int rc = rows_forward_impl(src, job_off, row_stride, nullptr, mask, m0, T1, tw_row, njobs, q, &box,
-                             acc, stream, row_chord);
+                             acc, stream, row_chord, half);
   if (rc) return rc;
   const double count = (double)njobs * (hu - hl) * (wu - wl);
   hipLaunchKernelGGL(xc_stats_finalize, dim3(1), dim3(1), 0, (hipStream_t)stream, acc, count, m0, fix,

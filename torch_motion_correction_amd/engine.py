@@ -242,6 +242,11 @@ def _global_spectra(img, pl):
                       lambda: torch.arange(t, device=dev, dtype=torch.int64) * (h * w))
     fused = (planmod.native_rows(g) and planmod.native_height(g.H) and hl >= g.y0 and hu <= g.y0 + g.ny and wl >= g.x0
              and wu <= g.x1 and wl % 2 == 0 and wu % 2 == 0 and hu > hl and wu > wl)
+    # fp16 frames are read as they are by the wave-per-row K1 (4096 columns); any other shape widens once
+    half_ok = (img.dtype == torch.float16 and fused and w == 4096 and g.nkx <= 512 and g.ny % 8 == 0
+               and wl % 256 == 0 and wu % 256 == 0 and img.data_ptr() % 16 == 0)
+    if img.dtype != torch.float32 and not half_ok:
+        img = img.float()
     if not fused:
         return _forward_spectra(img, job_off, w, None, pl, central_box_stats(img))
     st = stream_ptr(dev)
@@ -250,15 +255,15 @@ def _global_spectra(img, pl):
     # true mean does, so one row of frame 0's box is enough (one small workgroup)
     acc = torch.empty(128, dtype=torch.float64, device=dev)  # 64 x {sum, sumsq}
     m0 = torch.empty(3, dtype=torch.float32, device=dev)
-    check(lib.mc_xc_provisional_mean(C.c_void_p(img.data_ptr() + 4 * (hl * w + wl)), wu - wl, ptr(m0), st),
-          "mc_xc_provisional_mean")
+    check(lib.mc_xc_provisional_mean_t(C.c_void_p(img.data_ptr() + img.element_size() * (hl * w + wl)),
+                                       storage_of(img), wu - wl, ptr(m0), st), "mc_xc_provisional_mean")
     fix = torch.empty(2, dtype=torch.float32, device=dev)
     out3 = torch.empty(3, dtype=torch.float32, device=dev)
     T1 = torch.empty((t, g.nkx, g.ny, 2), dtype=torch.float32, device=dev)
     S = torch.empty((t, g.nkx, g.nky, 2), dtype=torch.float32, device=dev)
-    check(lib.mc_xc_rows_forward_stats(ptr(img), ptr(job_off), w, ptr(pl.mask), ptr(m0), ptr(T1),
-                                       ptr(pl.tw_row), t, g, hl, hu, wl, wu, ptr(acc), ptr(fix),
-                                       ptr(out3), ptr(_box_chords(pl, hl, hu, wl, wu)), st),
+    check(lib.mc_xc_rows_forward_stats_t(ptr(img), storage_of(img), ptr(job_off), w, ptr(pl.mask), ptr(m0), ptr(T1),
+                                         ptr(pl.tw_row), t, g, hl, hu, wl, wu, ptr(acc), ptr(fix),
+                                         ptr(out3), ptr(_box_chords(pl, hl, hu, wl, wu)), st),
           "mc_xc_rows_forward_stats")
     check(lib.mc_xc_cols_forward_fix(ptr(T1), ptr(pl.filt), ptr(S), ptr(pl.tw_col), t, g, ptr(fix),
                                      ptr(mhat), st), "mc_xc_cols_forward_fix")
@@ -472,8 +477,8 @@ def warp(img, lattices, pixel_spacing, want_frames=True, want_sum=False, rigid=F
     t, h, w = img.shape
     dev = img.device
     _, _, GH, GW = lattices.shape
-    if rigid and img.dtype != torch.float32:
-        img = img.float()  # the rigid kernel reads fp32 (BASELINE C2); fp16 stacks are widened once
+    if rigid and img.dtype == torch.float16 and (w % 8 or img.data_ptr() % 16):
+        img = img.float()  # fp16 rows that are not whole 8-sample units: widened once
     frames = torch.empty((t, h, w), dtype=torch.float32, device=dev) if want_frames else None
     total = torch.empty((h, w), dtype=torch.float32, device=dev) if want_sum else None  # the kernels store it
     nbytes = C.c_int64(0)
@@ -481,13 +486,12 @@ def warp(img, lattices, pixel_spacing, want_frames=True, want_sum=False, rigid=F
         shifts_px = (lattices[:, :, 0, 0] / pixel_spacing).contiguous()  # shifts_angstroms / ps
         check(lib.mc_warp_rigid_scratch_bytes(t, h, w, C.byref(nbytes)), "mc_warp_rigid_scratch_bytes")
         scratch = torch.empty((nbytes.value + 3) // 4, dtype=torch.float32, device=dev)
+        args = (ptr(img), storage_of(img), t, h, w, ptr(shifts_px), ptr(scratch), ptr(frames), ptr(total))
         if RIGID_KERNEL_HOOK is None:
-            check(lib.mc_warp_rigid(ptr(img), t, h, w, ptr(shifts_px), ptr(scratch), ptr(frames),
-                                    ptr(total), stream_ptr(dev)), "mc_warp_rigid")
+            check(lib.mc_warp_rigid_phase_t(*args, 0, stream_ptr(dev)), "mc_warp_rigid")
         else:  # instrumentation: the hook brackets the resampling kernel alone (bench.py)
-            args = (ptr(img), t, h, w, ptr(shifts_px), ptr(scratch), ptr(frames), ptr(total))
-            check(lib.mc_warp_rigid_phase(*args, 1, stream_ptr(dev)), "mc_warp_rigid_phase")
-            RIGID_KERNEL_HOOK(lambda: check(lib.mc_warp_rigid_phase(*args, 2, stream_ptr(dev)),
+            check(lib.mc_warp_rigid_phase_t(*args, 1, stream_ptr(dev)), "mc_warp_rigid_phase")
+            RIGID_KERNEL_HOOK(lambda: check(lib.mc_warp_rigid_phase_t(*args, 2, stream_ptr(dev)),
                                             "mc_warp_rigid_phase"))
         return frames, total
     check(lib.mc_warp_scratch_bytes(t, h, w, GH, GW, C.byref(nbytes)), "mc_warp_scratch_bytes")

@@ -114,7 +114,7 @@ class MoviePipeline:
 
     def run(self, movies: Iterable[torch.Tensor],
             around_warp: Optional[Callable[[Callable[[], object]], object]] = None) -> list[MovieResult]:
-        """Process `movies` ((t,h,w) float32 tensors on the pipeline's device) in order and
+        """Process `movies` ((t,h,w) float32 or float16 tensors on the pipeline's device) in order and
         return every result, ready for use on the caller's current stream."""
         results = list(self.iterate(movies, around_warp))
         if self.overlap:
@@ -128,8 +128,10 @@ class MoviePipeline:
     def _check(self, img: torch.Tensor) -> torch.Tensor:
         if img.dim() != 3:
             raise ValueError(f"expected a (t, h, w) stack, got shape {tuple(img.shape)}")
-        if img.device != self.device or img.dtype != torch.float32 or not img.is_contiguous():
-            img = img.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        # fp16 stacks stay fp16: K1 (4096-column frames) and the rigid warp read the 16-bit samples
+        dtype = torch.float16 if img.dtype == torch.float16 else torch.float32
+        if img.device != self.device or img.dtype != dtype or not img.is_contiguous():
+            img = img.detach().to(device=self.device, dtype=dtype).contiguous()
         return img
 
 
