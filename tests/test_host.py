@@ -227,6 +227,37 @@ def test_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.mc_warp_frames(None, 1, 64, 64, None, 10, 10, 1.0, None, None, None, None) == -1
 
 
+def test_full_spectrum_and_storage_entry_points_validate_on_the_host():
+    """The round-2 entry points (row-major full-spectrum transforms, fp16 storage tags) check sizes,
+    pointers and storage tags before any launch: pitch rule, supported row / column lengths (powers of
+    two and the K3 formats), MC_ERR_ARG for null pointers, MC_ERR_UNSUPPORTED for sizes the library has
+    no kernel for and for storage types that are not read natively."""
+    lib = _lib.load()
+    one = ctypes.c_void_p(16)  # a non-null, 16-byte aligned address: argument checks never dereference it
+    assert [lib.mc_full_spectrum_pitch(w) for w in (64, 4096, 5760, 11520)] == [48, 2064, 2896, 5776]
+    for (h, w) in ((4096, 4096), (256, 64), (4092, 5760), (8184, 11520), (4092, 4096), (256, 11520)):
+        pitch = lib.mc_full_spectrum_pitch(w)
+        assert lib.mc_full_rows_forward(None, one, w, one, one, 1, h, w, pitch, None) == -1  # null src
+        assert lib.mc_full_cols_shift(None, one, one, 1.0, 1, h, w, pitch, None) == -1
+        assert lib.mc_full_rows_inverse(one, None, one, w, one, 1, h, w, pitch, None) == -1
+        assert lib.mc_full_cols_dose(one, 0, 0, 1, one, one, h, w, pitch, 1.0, 0.0, 1.0, 300.0, 1, 1, 1.0, None) == -1
+    for (h, w) in ((4000, 4096), (4096, 4000), (128, 64), (8192, 64), (4092, 32)):  # no kernel for these
+        pitch = lib.mc_full_spectrum_pitch(w)
+        assert lib.mc_full_rows_forward(one, one, w, one, one, 1, h, w, pitch, None) == -2
+        assert lib.mc_full_cols_shift(one, one, one, 1.0, 1, h, w, pitch, None) == -2
+    assert lib.mc_full_rows_forward(one, one, 4096, one, one, 1, 4096, 4096, 2049, None) == -2  # pitch rule
+    # storage tags: 2 = fp16, 3 = fp32 are read natively; raw detector types go through mc_condition_movie
+    n = ctypes.c_int64(0)
+    assert lib.mc_warp_rigid_scratch_bytes(2, 64, 64, ctypes.byref(n)) == 0
+    assert lib.mc_warp_rigid_phase_t(one, 0, 2, 64, 64, one, one, one, one, 0, None) == -2   # u8 frames
+    assert lib.mc_warp_rigid_phase_t(one, 2, 2, 64, 60, one, one, one, one, 0, None) == -2   # fp16, w % 8 != 0
+    assert lib.mc_warp_rigid_phase_t(one, 3, 2, 64, 64, None, one, one, one, 0, None) == -1  # null shifts
+    assert lib.mc_xc_provisional_mean_t(one, 1, 16, one, None) == -2 and lib.mc_xc_provisional_mean_t(None, 2, 16, one, None) == -1
+    g = plan.xc_geometry(4096, 4096, 0.1, 1024, 512)
+    assert lib.mc_xc_rows_forward_stats_t(one, 1, one, 4096, one, one, one, one, 1, g, 1024, 3072, 1024, 3072, one,
+                                          one, one, None, None) == -2  # int16 frames are not read natively
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "torch_motion_correction_amd")
     for fn in os.listdir(pkg):
