@@ -329,7 +329,7 @@ __device__ __forceinline__ void wg_fft_inplace(cfloat* line, int tid, const cflo
 // 11520-column rows of K3 detectors, 4092 and 8184 = their row counts, 5120 and 10240 as chirp-z
 // lengths): the same one-line Stockham scheme as above with odd-radix passes and sub-transform
 // lengths that are no longer powers of two (k = j mod NS instead of a mask).  Radices: the primes
-// above 5 first (largest first), then 8 while N allows, then 4, 5, 3, 2.
+// above 5 first (largest first), then 8 while N allows, then 4, 9, 10, 5, 3, 2.
 // tw = exp(-2 pi i k / (N tw_stride)).
 // =====================================================================================
 template <int DIR>
@@ -422,9 +422,54 @@ __device__ __forceinline__ void bfly_prime(cfloat* a) {
   }
 }
 
+// 9 = 3 x 3 (Cooley-Tukey inside the registers: three radix-3 butterflies over n1, the three twiddles
+// W_9^{n2 k1}, three radix-3 butterflies over n2) and 10 = 2 x 5 (prime-factor map, no twiddles):
+// 2880 = 8 8 9 5 and 5760 = 8 8 9 10 take four passes instead of five / six.
+template <int DIR>
+__device__ __forceinline__ void bfly9(cfloat* a) {
+  // W_9^m = exp(DIR 2 pi i m / 9)
+  const float c1 = 0.76604444311897803520f, s1 = 0.64278760968653932632f;   // m = 1
+  const float c2 = 0.17364817766693034885f, s2 = 0.98480775301220805937f;   // m = 2
+  const float c4 = -0.93969262078590838405f, s4 = 0.34202014332566873304f;  // m = 4
+  cfloat t[3][3];  // [n2][k1]
+#pragma unroll
+  for (int n2 = 0; n2 < 3; ++n2) {
+    cfloat u[3] = {a[n2], a[3 + n2], a[6 + n2]};
+    bfly3<DIR>(u);
+    t[n2][0] = u[0]; t[n2][1] = u[1]; t[n2][2] = u[2];
+  }
+  const float sg = DIR < 0 ? -1.f : 1.f;
+  t[1][1] = cmul(t[1][1], cmake(c1, sg * s1));
+  t[1][2] = cmul(t[1][2], cmake(c2, sg * s2));
+  t[2][1] = cmul(t[2][1], cmake(c2, sg * s2));
+  t[2][2] = cmul(t[2][2], cmake(c4, sg * s4));
+#pragma unroll
+  for (int k1 = 0; k1 < 3; ++k1) {
+    cfloat u[3] = {t[0][k1], t[1][k1], t[2][k1]};
+    bfly3<DIR>(u);
+    a[k1] = u[0]; a[k1 + 3] = u[1]; a[k1 + 6] = u[2];
+  }
+}
+
+template <int DIR>
+__device__ __forceinline__ void bfly10(cfloat* a) {
+  // n = (5 n1 + 2 n2) mod 10, k = (5 k1 + 6 k2) mod 10
+  cfloat y0[5] = {a[0], a[2], a[4], a[6], a[8]};   // n1 = 0: n = 2 n2
+  cfloat y1[5] = {a[5], a[7], a[9], a[1], a[3]};   // n1 = 1: n = 5 + 2 n2 mod 10
+  bfly5<DIR>(y0);
+  bfly5<DIR>(y1);
+#pragma unroll
+  for (int k2 = 0; k2 < 5; ++k2) {
+    a[(6 * k2) % 10] = cadd(y0[k2], y1[k2]);      // k1 = 0
+    a[(5 + 6 * k2) % 10] = csub(y0[k2], y1[k2]);  // k1 = 1
+  }
+}
+
 template <int R, int DIR>
 __device__ __forceinline__ void bfly_any(cfloat* a) {
-  if constexpr (R == 5) bfly5<DIR>(a);
+  if constexpr (R == 9) bfly9<DIR>(a);
+  else if constexpr (R == 10) bfly10<DIR>(a);
+  else if constexpr (R == 5) bfly5<DIR>(a);
   else if constexpr (R == 3) bfly3<DIR>(a);
   else if constexpr (R == 7 || R == 11 || R == 13 || R == 31) bfly_prime<R, DIR>(a);
   else bfly<R, DIR>(a);
@@ -433,7 +478,8 @@ __device__ __forceinline__ void bfly_any(cfloat* a) {
 // radix of the next pass: the large primes first (the first pass has no twiddles), then 8, 4, 5, 3, 2
 __host__ __device__ constexpr int smooth_radix(int rem) {
   return rem % 31 == 0 ? 31 : rem % 13 == 0 ? 13 : rem % 11 == 0 ? 11 : rem % 7 == 0 ? 7 : rem % 8 == 0 ? 8
-       : rem % 4 == 0 ? 4 : rem % 5 == 0 ? 5 : rem % 3 == 0 ? 3 : rem % 2 == 0 ? 2 : 0;
+       : rem % 4 == 0 ? 4 : rem % 9 == 0 ? 9 : rem % 10 == 0 ? 10 : rem % 5 == 0 ? 5 : rem % 3 == 0 ? 3
+       : rem % 2 == 0 ? 2 : 0;
 }
 __host__ __device__ constexpr bool is_smooth(int n) {
   while (n % 2 == 0) n /= 2;
