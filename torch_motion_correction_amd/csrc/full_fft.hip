@@ -262,8 +262,16 @@ __global__ __launch_bounds__(WG) void full_cols_dose(const cfloat* __restrict__ 
   const int tid = threadIdx.x;
   const int kx0 = full_col_of_block<NC>(blockIdx.x, pitch);
   if (kx0 > W / 2) return;  // padding columns of the pitch (workgroup-uniform)
+  // mixed-radix lines (one column per workgroup): the exposure exponents of the column's rows sit in
+  // LDS behind the line instead of in 24-33 registers per thread
+  constexpr bool MH_LDS = (H & (H - 1)) != 0;
+  static_assert(!MH_LDS || NC == 1, "mixed-radix exposure pass: one column per workgroup");
+  float* mhl = reinterpret_cast<float*>(lines[0] + NC * lds_len(H));
+  if constexpr (MH_LDS) {
+    for (int ky = tid; ky < H; ky += WG) mhl[ky] = full_dose_mh(kx0, ky, W, H, pixel_size, vscale);
+  }
   cfloat acc[NC][SLOTS];
-  float mh[NC][SLOTS];
+  float mh[NC][MH_LDS ? 1 : SLOTS];
   int kys[SLOTS];  // output row of a slot (power-of-two lines: recorded; mixed radix: computed, see below)
   int nslots = 0;
 #pragma unroll
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(WG) void full_cols_dose(const cfloat* __restrict__ 
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
       acc[c][s] = cmake(0.f, 0.f);
-      mh[c][s] = 0.f;
+      if constexpr (!MH_LDS) mh[c][s] = 0.f;
     }
   for (int j = 0; j < nframes; ++j) {
     full_cols_load<H, NC, WG>(lines, S + (int64_t)j * H * pitch + kx0, pitch, tid);
@@ -284,11 +292,17 @@ __global__ __launch_bounds__(WG) void full_cols_dose(const cfloat* __restrict__ 
       cfloat* line = lines[c];
       auto rd = [&](int i) { return line[lpad(i)]; };
       auto take3 = [&](int ky, cfloat v, int slot) {
-        if (j == 0) {
-          if constexpr ((H & (H - 1)) == 0) kys[slot] = ky;
-          mh[c][slot] = full_dose_mh(kx0 + c, ky, W, H, pixel_size, vscale);
+        float m;
+        if constexpr (MH_LDS) {
+          m = mhl[ky];
+        } else {
+          if (j == 0) {
+            kys[slot] = ky;
+            mh[c][slot] = full_dose_mh(kx0 + c, ky, W, H, pixel_size, vscale);
+          }
+          m = mh[c][slot];
         }
-        const float q = expf(mh[c][slot] * dose);
+        const float q = expf(m * dose);
         acc[c][slot].x += q * v.x;
         acc[c][slot].y += q * v.y;
       };
@@ -330,9 +344,10 @@ __global__ __launch_bounds__(WG) void full_cols_dose(const cfloat* __restrict__ 
         a.y += prev.y;
       }
       if (last) {
+        const float m = MH_LDS ? mhl[ky] : mh[c][MH_LDS ? 0 : s];
         float qq = 0.f;
         for (int f = 0; f < total_frames; ++f) {
-          const float q = expf(mh[c][s] * (pre_exposure + dose_per_frame * (float)(f + 1)));
+          const float q = expf(m * (pre_exposure + dose_per_frame * (float)(f + 1)));
           qq += q * q;
         }
         const float r = scale / sqrtf(qq);
@@ -605,7 +620,7 @@ int mc_full_cols_dose(const void* S, int nframes, int frame0, int total_frames, 
     // on top of the radix-31 pass need 300 registers: one wavefront per SIMD)
     constexpr int NC = (L & (L - 1)) ? 1 : full_nc<L>(), WG = full_wg<L>();
     auto k = full_cols_dose<L, NC, WG>;
-    const size_t lds = NC * sizeof(cfloat) * (size_t)lds_len(L);
+    const size_t lds = NC * sizeof(cfloat) * (size_t)lds_len(L) + ((L & (L - 1)) ? sizeof(float) * (size_t)L : 0);
     MC_FULL_SET_LDS(k, lds);
     hipLaunchKernelGGL(k, dim3(pitch / NC), dim3(WG), lds, (hipStream_t)stream, (const cfloat*)S, nframes, frame0,
                        total_frames, (cfloat*)A, W, pitch, (const cfloat*)tw_col, pixel_size, pre_exposure,

@@ -465,9 +465,34 @@ __device__ __forceinline__ void bfly10(cfloat* a) {
   }
 }
 
+// 12 = 3 x 4 and 24 = 3 x 8 by the prime-factor map (no twiddles): the tails of 4092 = 31 11 12 and
+// 8184 = 31 11 24, three passes per column instead of four.
+//   12: n = (4 n1 + 3 n2) mod 12, k = (4 k1 + 9 k2) mod 12;  24: n = (8 n1 + 3 n2) mod 24, k = (16 k1 + 9 k2) mod 24
+template <int R2, int DIR>
+__device__ __forceinline__ void bfly_pfa3(cfloat* a) {
+  constexpr int R = 3 * R2;                    // R2 = 4 or 8
+  constexpr int KA = R2 == 4 ? 4 : 16;         // k = (KA k1 + 9 k2) mod R
+  cfloat y[3][R2];                             // [n1][n2] -> after the R2-point transforms [n1][k2]
+#pragma unroll
+  for (int n1 = 0; n1 < 3; ++n1) {
+#pragma unroll
+    for (int n2 = 0; n2 < R2; ++n2) y[n1][n2] = a[(R2 * n1 + 3 * n2) % R];
+    bfly<R2, DIR>(y[n1]);
+  }
+#pragma unroll
+  for (int k2 = 0; k2 < R2; ++k2) {
+    cfloat u[3] = {y[0][k2], y[1][k2], y[2][k2]};
+    bfly3<DIR>(u);
+#pragma unroll
+    for (int k1 = 0; k1 < 3; ++k1) a[(KA * k1 + 9 * k2) % R] = u[k1];
+  }
+}
+
 template <int R, int DIR>
 __device__ __forceinline__ void bfly_any(cfloat* a) {
-  if constexpr (R == 9) bfly9<DIR>(a);
+  if constexpr (R == 12) bfly_pfa3<4, DIR>(a);
+  else if constexpr (R == 24) bfly_pfa3<8, DIR>(a);
+  else if constexpr (R == 9) bfly9<DIR>(a);
   else if constexpr (R == 10) bfly10<DIR>(a);
   else if constexpr (R == 5) bfly5<DIR>(a);
   else if constexpr (R == 3) bfly3<DIR>(a);
@@ -477,7 +502,8 @@ __device__ __forceinline__ void bfly_any(cfloat* a) {
 
 // radix of the next pass: the large primes first (the first pass has no twiddles), then 8, 4, 5, 3, 2
 __host__ __device__ constexpr int smooth_radix(int rem) {
-  return rem % 31 == 0 ? 31 : rem % 13 == 0 ? 13 : rem % 11 == 0 ? 11 : rem % 7 == 0 ? 7 : rem % 8 == 0 ? 8
+  return rem % 31 == 0 ? 31 : rem % 13 == 0 ? 13 : rem % 11 == 0 ? 11 : rem % 7 == 0 ? 7
+       : rem == 24 ? 24 : rem == 12 ? 12 : rem % 8 == 0 ? 8
        : rem % 4 == 0 ? 4 : rem % 9 == 0 ? 9 : rem % 10 == 0 ? 10 : rem % 5 == 0 ? 5 : rem % 3 == 0 ? 3
        : rem % 2 == 0 ? 2 : 0;
 }
