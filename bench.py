@@ -180,6 +180,25 @@ def main():
             engine.RIGID_KERNEL_HOOK = None
         torch.cuda.synchronize()
         solo_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    # what this box sustains on a plain copy of buffers larger than the Infinity Cache (read + write
+    # bytes per second): the practical ceiling next to the 8 TB/s spec the fractions are quoted against
+    copy_rate = None
+    if rank == 0:
+        try:
+            a0 = torch.empty(1 << 28, dtype=torch.float32, device=dev)  # 1 GiB
+            b0 = torch.empty_like(a0)
+            b0.copy_(a0)
+            torch.cuda.synchronize()
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            for _ in range(5):
+                b0.copy_(a0)
+            c1.record()
+            torch.cuda.synchronize()
+            copy_rate = 5 * 2 * a0.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+            del a0, b0
+        except Exception:
+            copy_rate = None
     shifts = (out.field[:, :, 0, 0].transpose(0, 1) / 1.0).cpu()
     shifts_ok = bool(torch.equal(shifts, expect))
     warp_ms = sum(a.elapsed_time(b) for a, b in warp_events) / max(len(warp_events), 1)
@@ -317,6 +336,10 @@ def main():
                 "ms_per_launch_unshared": solo_ms,
                 "frac_unshared": (alg_bytes / (solo_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if solo_ms else None,
                 "whole_step_frac": 12.0 * h * w * t / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                # context, measured in this run: a torch copy of 1 GiB buffers (read + write GB/s); the
+                # kernel's ACTUAL traffic (`traffic`) over its unshared launch time sits on that line
+                "box_copy_rate": copy_rate,
+                "actual_traffic_rate_unshared": (traffic / (solo_ms * 1e-3) / 1e9) if (traffic and solo_ms) else None,
             },
             "cpu_baseline": cpu,
             "secondary": secondary,
