@@ -1526,6 +1526,34 @@ def test_c3_full_frame_size_against_oracle(mc, dev):
     assert float(total.std()) > 0.8 * t * float(st[0].std()) * 0.7
 
 
+@pytest.mark.parametrize("t,h,w", [(6, 4092, 5760), (3, 8184, 11520)])
+def test_k3_formats_global_estimate_known_drift(mc, dev, t, h, w):
+    """estimate_global_motion on the K3 detector's two frame formats (BASELINE C3 / C5 frame sizes): the
+    shifts equal the drift the stack was built with, with the direct mixed-radix lines (rows of
+    2880 / 5760 points: radix 8 8 9 5 / 8 8 9 10; columns of 4092 / 8184 points: radix 31 11 12 / 31 11 24)
+    and with the chirp-z lines they replace; zero-dose exposure weighting of the same frames is the
+    plain sum / sqrt(t) (row-major mixed-radix full spectrum against a direct sum)."""
+    import bench
+    from torch_motion_correction_amd import plan
+
+    st, dy, dx = bench.synth_stack(t, h, w, 77, dev)
+    want_y = [float(d - dy[t // 2]) for d in dy]
+    want_x = [float(d - dx[t // 2]) for d in dx]
+    f = mc.estimate_global_motion(st, 1.0).cpu()
+    assert f[0, :, 0, 0].tolist() == want_y and f[1, :, 0, 0].tolist() == want_x
+    try:
+        plan.USE_DIRECT_LINES = False
+        plan._LINES.clear()
+        fc = mc.estimate_global_motion(st, 1.0).cpu()
+    finally:
+        plan.USE_DIRECT_LINES = True
+        plan._LINES.clear()
+    assert torch.equal(fc, f)
+    z = mc.dose_weighted_sum(st, 1.0, 0.0)
+    plain = st.sum(0) / t**0.5
+    assert float((z - plain).abs().max()) <= 1e-4 * float(plain.abs().max())
+
+
 def torch_gpu_correct_frame(frame, lattice, pixel_spacing):
     """The reference's _correct_frame op sequence (correct_motion.py:81-185) executed by torch's OWN
     ROCm operators on the GPU: an independent fp32 implementation for sizes the CPU oracle does not
