@@ -292,6 +292,48 @@ def main():
             del st3, f3, s3, fl
         except Exception as e:  # never let the secondary workload break the headline line
             secondary = {"error": repr(e)}
+        # BASELINE.json configs[4]: 60 x 8184 x 11520 stored as fp16, 1024-px patches (14 x 21), B-spline
+        # warp, plain and dose-weighted sum -- one flow, reported next to the C3 numbers
+        try:
+            torch.cuda.empty_cache()
+            t5, h5, w5, pad = 60, 8184, 11520, 64
+            g5 = torch.Generator(device=dev).manual_seed(5)
+            base5 = torch.randn(h5 + 2 * pad, w5 + 2 * pad, generator=g5, device=dev)
+            dy5 = torch.round(torch.linspace(-6, 8, t5)).long().tolist()
+            dx5 = torch.round(torch.linspace(5, -4, t5)).long().tolist()
+            st5 = torch.empty((t5, h5, w5), dtype=torch.float16, device=dev)
+            for f in range(t5):
+                st5[f] = (base5[pad - dy5[f]: pad - dy5[f] + h5, pad - dx5[f]: pad - dx5[f] + w5]
+                          + torch.randn(h5, w5, generator=g5, device=dev)).half()
+            del base5
+            c5t = []
+            for _ in range(2):
+                torch.cuda.synchronize()
+                torch.cuda.reset_peak_memory_stats()
+                c0 = time.perf_counter()
+                f5, _ = mc.estimate_motion_cross_correlation_patches(st5, 1.0, patch_sidelength=1024)
+                torch.cuda.synchronize()
+                c1 = time.perf_counter()
+                s5 = mc.motion_correct_sum(st5, f5, 1.0, grid_type="bspline")
+                torch.cuda.synchronize()
+                c2 = time.perf_counter()
+                d5 = mc.motion_correct_sum(st5, f5, 1.0, grid_type="bspline", dose_per_frame=1.0)
+                torch.cuda.synchronize()
+                c5t.append((c1 - c0, c2 - c1, time.perf_counter() - c2))
+            est5, cor5, dose5 = c5t[-1]
+            secondary["c5"] = {
+                "workload": f"{t5}-frame {h5}x{w5} fp16-stored movie, 1024-px patch estimate "
+                            f"({f5.shape[2]}x{f5.shape[3]} patches) + B-spline warp + frame sum / dose-weighted sum",
+                "estimate_ms": 1e3 * est5, "correct_sum_ms": 1e3 * cor5, "correct_dose_weighted_sum_ms": 1e3 * dose5,
+                "frames_per_s_plain_sum": t5 / (est5 + cor5), "frames_per_s_dose_weighted": t5 / (est5 + dose5),
+                "peak_hbm_GB": torch.cuda.max_memory_allocated() / 1e9,
+                "sums_finite": bool(torch.isfinite(s5).all() and torch.isfinite(d5).all()),
+            }
+            del st5, f5, s5, d5
+            torch.cuda.empty_cache()
+        except Exception as e:
+            if isinstance(secondary, dict):
+                secondary["c5"] = {"error": repr(e)}
 
     traffic = None
     tp = os.path.join(ROOT, "profiles", "warp_traffic.json")
