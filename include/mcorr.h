@@ -348,6 +348,13 @@ int mc_full_cols_shift(void* S, const float* shifts, const void* tw_col, float s
 int mc_full_cols_dose(const void* S, int nframes, int frame0, int total_frames, void* A, const void* tw_col,
                       int H, int W, int pitch, float pixel_size, float pre_exposure, float dose_per_frame,
                       float voltage, int first, int last, float scale, void* stream);
+/* Column-major copy of a chunk of row-major spectra, ST[job][kx][y] (kx <= W/2), and the exposure-weighted
+ * pass reading it (H = 4096, 4092 or 8184: contiguous columns instead of 8 bytes of every 128-byte line;
+ * A stays row-major; otherwise as mc_full_cols_dose). */
+int mc_full_transpose(const void* S, void* ST, int njobs, int H, int W, int pitch, void* stream);
+int mc_full_cols_dose_cm(const void* ST, int nframes, int frame0, int total_frames, void* A, const void* tw_col,
+                         int H, int W, int pitch, float pixel_size, float pre_exposure, float dose_per_frame,
+                         float voltage, int first, int last, float scale, void* stream);
 int mc_full_rows_inverse(const void* S, float* out, const int64_t* out_off, int64_t out_stride,
                          const void* tw_row, int njobs, int H, int W, int pitch, void* stream);
 

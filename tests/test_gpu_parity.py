@@ -1771,6 +1771,7 @@ def test_row_major_fourier_shift(mc, dev, shape):
                                                   ((5, 512, 256), 1.3, 0.8, 2.0, 200.0),
                                                   ((3, 256, 1024), 0.83, 2.5, 0.5, 100.0),
                                                   ((5, 4092, 64), 1.0, 1.2, 0.0, 300.0),
+                                                  ((5, 4096, 128), 0.9, 1.1, 0.5, 300.0),
                                                   ((4, 8184, 128), 0.5, 0.9, 1.0, 300.0),
                                                   ((3, 256, 5760), 1.1, 1.0, 0.0, 200.0)])
 def test_row_major_dose_weighted_sum(mc, dev, shape, ps, dose, pre, kv):
@@ -1796,3 +1797,9 @@ def test_row_major_dose_weighted_sum(mc, dev, shape, ps, dose, pre, kv):
     finally:
         engine.FULL_ROW_MAJOR = True
     assert float((got - old).abs().max()) <= 2e-5 * float(ref.abs().max())
+    try:  # 4096 / 4092 rows: the column pass fed from the column-major copy (default) == fed from the rows
+        engine.DOSE_COLUMN_MAJOR = False
+        rowfed = mc.dose_weighted_sum(m.to(dev), ps, dose, pre_exposure=pre, voltage=kv).cpu()
+    finally:
+        engine.DOSE_COLUMN_MAJOR = True
+    assert float((got - rowfed).abs().max()) <= 2e-6 * float(ref.abs().max())

@@ -79,6 +79,8 @@ SIGNATURES = {
     "mc_full_rows_forward": [vp, vp, i64, vp, vp, i32, i32, i32, i32, vp],
     "mc_full_cols_shift": [vp, vp, vp, f32, i32, i32, i32, i32, vp],
     "mc_full_cols_dose": [vp, i32, i32, i32, vp, vp, i32, i32, i32, f32, f32, f32, f32, i32, i32, f32, vp],
+    "mc_full_cols_dose_cm": [vp, i32, i32, i32, vp, vp, i32, i32, i32, f32, f32, f32, f32, i32, i32, f32, vp],
+    "mc_full_transpose": [vp, vp, i32, i32, i32, i32, vp],
     "mc_full_rows_inverse": [vp, vp, vp, i64, vp, i32, i32, i32, i32, vp],
     "mc_fourier_shift_cols_inverse": [vp, vp, vp, vp, vp, f32, i32, GP, vp],
     "mc_xc_rows_inverse_store": [vp, vp, vp, i64, vp, i32, GP, vp],

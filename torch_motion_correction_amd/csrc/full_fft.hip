@@ -142,7 +142,7 @@ __device__ __forceinline__ int full_col_of_block(int b, int pitch) {
 // thread's loads are issued before the first LDS write (a rolled loop waits for every load in turn:
 // H / WG memory round trips per column instead of one).
 template <int H, int NC, int WG>
-__device__ __forceinline__ void full_cols_load(cfloat* const* lines, const cfloat* base, int pitch, int tid) {
+__device__ __forceinline__ void full_cols_load(cfloat* const* lines, const cfloat* base, int64_t pitch, int tid) {
   constexpr int IT = (H + WG - 1) / WG;
   if constexpr (NC == 2) {
     float4 v[IT];
@@ -249,13 +249,16 @@ __host__ __device__ constexpr int full_last_slots() {
   return ((H / r + WG - 1) / WG) * r;  // iterations of the last pass x its radix
 }
 
+// Input strides (in complex elements): element (frame j, row y, column kx) of S sits at
+// j sf + y sr + kx sc -- row-major spectra: (H pitch, pitch, 1); column-major copies made by
+// full_transpose: (ncols H, 1, H), read with NC = 1 as contiguous columns.
 template <int H, int NC, int WG>
 __global__ __launch_bounds__(WG) void full_cols_dose(const cfloat* __restrict__ S, int nframes, int frame0,
                                                         int total_frames, cfloat* __restrict__ A, int W,
                                                         int pitch, const cfloat* __restrict__ tw_col,
                                                         float pixel_size, float pre_exposure,
                                                         float dose_per_frame, float vscale, int first, int last,
-                                                        float scale) {
+                                                        float scale, int64_t sf, int64_t sr, int64_t sc) {
   constexpr int SLOTS = full_last_slots<H, WG>();
   extern __shared__ __attribute__((aligned(16))) char smem_fc[];
   cfloat* lines[2] = {reinterpret_cast<cfloat*>(smem_fc), reinterpret_cast<cfloat*>(smem_fc) + lds_len(H)};
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(WG) void full_cols_dose(const cfloat* __restrict__ 
       if constexpr (!MH_LDS) mh[c][s] = 0.f;
     }
   for (int j = 0; j < nframes; ++j) {
-    full_cols_load<H, NC, WG>(lines, S + (int64_t)j * H * pitch + kx0, pitch, tid);
+    full_cols_load<H, NC, WG>(lines, S + (int64_t)j * sf + (int64_t)kx0 * sc, sr, tid);
     __syncthreads();
     const float dose = pre_exposure + dose_per_frame * (float)(frame0 + j + 1);
 #pragma unroll
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(MC_WG) void full_cols_dose_r16(const cfloat* __rest
                                                             int pitch, const cfloat* __restrict__ tw_col,
                                                             float pixel_size, float pre_exposure,
                                                             float dose_per_frame, float vscale, int first, int last,
-                                                            float scale) {
+                                                            float scale, int64_t sf, int64_t sr, int64_t sc) {
   // NC = 1: one column per workgroup (8-byte loads; 130 registers instead of 256 + spills to AGPRs:
   // three wavefronts per SIMD instead of one)
   constexpr int H = 4096;
@@ -441,16 +444,16 @@ __global__ __launch_bounds__(MC_WG) void full_cols_dose_r16(const cfloat* __rest
       mh[c][k3] = full_dose_mh(kx0 + c, tid + 256 * k3, W, H, pixel_size, vscale);
     }
   for (int j = 0; j < nframes; ++j) {
-    const cfloat* base = S + (int64_t)j * H * pitch + kx0;
+    const cfloat* base = S + (int64_t)j * sf + (int64_t)kx0 * sc;
     cfloat v[NC][16];
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {
       if constexpr (NC == 2) {
-        const float4 q = *reinterpret_cast<const float4*>(base + (int64_t)(256 * n1 + tid) * pitch);
+        const float4 q = *reinterpret_cast<const float4*>(base + (int64_t)(256 * n1 + tid) * sr);
         v[0][n1] = cmake(q.x, q.y);
         v[1][n1] = cmake(q.z, q.w);
       } else {
-        v[0][n1] = base[(int64_t)(256 * n1 + tid) * pitch];
+        v[0][n1] = base[(int64_t)(256 * n1 + tid) * sr];
       }
     }
     const float dose = pre_exposure + dose_per_frame * (float)(frame0 + j + 1);
@@ -506,6 +509,39 @@ __global__ __launch_bounds__(MC_WG) void full_cols_dose_r16(const cfloat* __rest
           make_float4(acc[0][n1].x, acc[0][n1].y, acc[1][n1].x, acc[1][n1].y);
     else
       abase[(int64_t)(256 * n1 + tid) * pitch] = acc[0][n1];
+  }
+}
+
+// S[job][y][pitch] (row-major) -> ST[job][kx][y] (column-major, kx <= W/2) through 64 x 64 LDS tiles:
+// whole 512-byte row pieces in, whole 512-byte column pieces out.  The column passes use 8 or 16
+// bytes of every 128-byte line of a row-major spectrum (L2 -> L1 traffic 8-16x the data: what
+// bounds them); the exposure-weighted pass, which only READS the spectra of a chunk of frames,
+// is fed from this copy instead: contiguous columns, one read + write pass more, less time.
+__global__ __launch_bounds__(256) void full_transpose(const cfloat* __restrict__ S, cfloat* __restrict__ ST, int H,
+                                                      int ncols, int pitch) {
+  __shared__ __attribute__((aligned(16))) cfloat tile[64][66];
+  const int job = blockIdx.z;
+  const int y0 = blockIdx.y * 64, x0 = blockIdx.x * 64;
+  const cfloat* src = S + (int64_t)job * H * pitch;
+  cfloat* dst = ST + (int64_t)job * ncols * H;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8: a thread moves 2 bins at a time
+#pragma unroll
+  for (int r = ty; r < 64; r += 8) {
+    const int y = y0 + r, x = x0 + 2 * tx;
+    if (y < H && x < pitch) {  // pitch is a multiple of 16: whole pairs inside the row
+      const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)y * pitch + x);
+      tile[r][2 * tx] = cmake(v.x, v.y);
+      tile[r][2 * tx + 1] = cmake(v.z, v.w);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = ty; c < 64; c += 8) {
+    const int x = x0 + c, y = y0 + 2 * tx;
+    if (x < ncols && y < H) {  // H is even: whole pairs inside the column
+      const cfloat a = tile[2 * tx][c], b = tile[2 * tx + 1][c];
+      *reinterpret_cast<float4*>(dst + (int64_t)x * H + y) = make_float4(a.x, a.y, b.x, b.y);
+    }
   }
 }
 
@@ -601,18 +637,48 @@ int mc_full_cols_shift(void* S, const float* shifts, const void* tw_col, float s
   return mc_check_launch();
 }
 
+int mc_full_transpose(const void* S, void* ST, int njobs, int H, int W, int pitch, void* stream) {
+  if (!S || !ST || njobs < 1) return MC_ERR_ARG;
+  if (!full_sizes_ok(H, W, pitch) || (H & 1)) return MC_ERR_UNSUPPORTED;
+  const int ncols = W / 2 + 1;
+  hipLaunchKernelGGL(full_transpose, dim3((ncols + 63) / 64, (H + 63) / 64, njobs), dim3(256), 0, (hipStream_t)stream,
+                     (const cfloat*)S, (cfloat*)ST, H, ncols, pitch);
+  return mc_check_launch();
+}
+
+static int full_cols_dose_impl(const void* S, bool colmajor, int nframes, int frame0, int total_frames, void* A,
+                               const void* tw_col, int H, int W, int pitch, float pixel_size, float pre_exposure,
+                               float dose_per_frame, float voltage, int first, int last, float scale, void* stream);
+
 int mc_full_cols_dose(const void* S, int nframes, int frame0, int total_frames, void* A, const void* tw_col,
                       int H, int W, int pitch, float pixel_size, float pre_exposure, float dose_per_frame,
                       float voltage, int first, int last, float scale, void* stream) {
+  return full_cols_dose_impl(S, false, nframes, frame0, total_frames, A, tw_col, H, W, pitch, pixel_size, pre_exposure,
+                             dose_per_frame, voltage, first, last, scale, stream);
+}
+
+int mc_full_cols_dose_cm(const void* ST, int nframes, int frame0, int total_frames, void* A, const void* tw_col,
+                         int H, int W, int pitch, float pixel_size, float pre_exposure, float dose_per_frame,
+                         float voltage, int first, int last, float scale, void* stream) {
+  if (H != 4096 && H != 4092 && H != 8184) return MC_ERR_UNSUPPORTED;  // the one-column-per-workgroup kernels
+  return full_cols_dose_impl(ST, true, nframes, frame0, total_frames, A, tw_col, H, W, pitch, pixel_size, pre_exposure,
+                             dose_per_frame, voltage, first, last, scale, stream);
+}
+
+static int full_cols_dose_impl(const void* S, bool colmajor, int nframes, int frame0, int total_frames, void* A,
+                               const void* tw_col, int H, int W, int pitch, float pixel_size, float pre_exposure,
+                               float dose_per_frame, float voltage, int first, int last, float scale, void* stream) {
   if (!S || !A || !tw_col || nframes < 1 || frame0 < 0 || total_frames < frame0 + nframes || !(pixel_size > 0.f) ||
       !(dose_per_frame >= 0.f))
     return MC_ERR_ARG;
   if (!full_sizes_ok(H, W, pitch)) return MC_ERR_UNSUPPORTED;
   const float vscale = voltage >= 300.f ? 1.0f : (voltage >= 200.f ? 0.8f : 0.75f);
+  const int64_t sf = colmajor ? (int64_t)(W / 2 + 1) * H : (int64_t)H * pitch;
+  const int64_t sr = colmajor ? 1 : pitch, sc = colmajor ? H : 1;
   if (H == 4096) {
     hipLaunchKernelGGL(full_cols_dose_r16<1>, dim3(pitch), dim3(MC_WG), 0, (hipStream_t)stream, (const cfloat*)S,
                        nframes, frame0, total_frames, (cfloat*)A, W, pitch, (const cfloat*)tw_col, pixel_size,
-                       pre_exposure, dose_per_frame, vscale, first, last, scale);
+                       pre_exposure, dose_per_frame, vscale, first, last, scale, sf, sr, sc);
     return mc_check_launch();
   }
   MC_FULL_DISPATCH_COLS(H, {
@@ -624,7 +690,7 @@ int mc_full_cols_dose(const void* S, int nframes, int frame0, int total_frames, 
     MC_FULL_SET_LDS(k, lds);
     hipLaunchKernelGGL(k, dim3(pitch / NC), dim3(WG), lds, (hipStream_t)stream, (const cfloat*)S, nframes, frame0,
                        total_frames, (cfloat*)A, W, pitch, (const cfloat*)tw_col, pixel_size, pre_exposure,
-                       dose_per_frame, vscale, first, last, scale);
+                       dose_per_frame, vscale, first, last, scale, sf, sr, sc);
   });
   return mc_check_launch();
 }

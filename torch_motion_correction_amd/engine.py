@@ -591,6 +591,7 @@ def _fourier_shift_polyphase(img, shifts):
 
 
 FULL_ROW_MAJOR = True  # tests: False forces the pruned engine's transposed layout on power-of-two frames
+DOSE_COLUMN_MAJOR = True  # tests / A-B: False feeds the exposure-weighted pass from the row-major spectra
 
 
 def _full_row_major_ok(h, w):
@@ -641,8 +642,15 @@ def _dose_weighted_sum_row_major(img, pixel_spacing, dose_per_frame, pre_exposur
     pitch = lib.mc_full_spectrum_pitch(w)
     tw_row, tw_col = planmod.get_twiddles(w, dev), planmod.get_twiddles(h, dev)
     per_frame = h * pitch * 8
-    chunk = max(1, min(t, WORKSPACE_BYTES // per_frame))
+    # 4096 / 4092 rows: the exposure-weighted pass reads a column-major copy of the chunk's spectra
+    # (mc_full_transpose): contiguous columns instead of 8 bytes of every 128-byte line -- 4.4 -> 3.6 ms
+    # per 40 x 4096^2, 8.6 -> 7.4 ms per 40 x 4092 x 5760 with the copy's own read + write pass paid.
+    # Not for 8184 rows (14.4 -> 15.2 ms per 12 frames: that column kernel is bound by its radix-31
+    # pass on 512-thread workgroups, not by how it is fed).
+    colmajor = DOSE_COLUMN_MAJOR and h in (4096, 4092)
+    chunk = max(1, min(t, WORKSPACE_BYTES // ((2 if colmajor else 1) * per_frame)))
     S = torch.empty((chunk, h, pitch, 2), dtype=torch.float32, device=dev)
+    ST = torch.empty((chunk, w // 2 + 1, h, 2), dtype=torch.float32, device=dev) if colmajor else None
     A = torch.empty((h, pitch, 2), dtype=torch.float32, device=dev)
     st = stream_ptr(dev)
     for a in range(0, t, chunk):
@@ -654,10 +662,14 @@ def _dose_weighted_sum_row_major(img, pixel_spacing, dose_per_frame, pre_exposur
         off = torch.arange(first, first + n, device=dev, dtype=torch.int64) * (h * w)
         check(lib.mc_full_rows_forward(ptr(src), ptr(off), w, ptr(S), ptr(tw_row), n, h, w, pitch, st),
               "mc_full_rows_forward")
-        check(lib.mc_full_cols_dose(ptr(S), n, a, t, ptr(A), ptr(tw_col), h, w, pitch, float(pixel_spacing),
-                                    float(pre_exposure), float(dose_per_frame), float(voltage),
-                                    1 if a == 0 else 0, 1 if a + n >= t else 0, 1.0 / (h * w), st),
-              "mc_full_cols_dose")
+        dose_args = (n, a, t, ptr(A), ptr(tw_col), h, w, pitch, float(pixel_spacing), float(pre_exposure),
+                     float(dose_per_frame), float(voltage), 1 if a == 0 else 0, 1 if a + n >= t else 0,
+                     1.0 / (h * w), st)
+        if colmajor:
+            check(lib.mc_full_transpose(ptr(S), ptr(ST), n, h, w, pitch, st), "mc_full_transpose")
+            check(lib.mc_full_cols_dose_cm(ptr(ST), *dose_args), "mc_full_cols_dose_cm")
+        else:
+            check(lib.mc_full_cols_dose(ptr(S), *dose_args), "mc_full_cols_dose")
         del src
     out = torch.empty((h, w), dtype=torch.float32, device=dev)
     off0 = torch.zeros(1, device=dev, dtype=torch.int64)
