@@ -18,6 +18,7 @@
 #pragma clang fp contract(off)
 #include <type_traits>
 #include <stdlib.h>
+#include <stdio.h>
 #include "mc_common.h"
 #include "mcorr.h"
 
@@ -640,6 +641,25 @@ __device__ __forceinline__ float rigid_dot5(float a0, float b0, float a1, float 
   return __builtin_fmaf(a4, b4, r);
 }
 
+#ifdef MC_RIGID_STAMP
+__device__ unsigned long long g_rigid_stamps[8];
+#define RSTAMP(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define RSTAMP(v) do { } while (0)
+#endif
+typedef float rigid_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void rigid_store4(float* p, float a, float b, float c, float d) {
+  // corrected frames are written once and never read again by this kernel: non-temporal stores
+  // (fused launch 1.25 -> 1.15 ms at 40 x 4096^2, frames only 0.98 -> 0.95; scripts/ubench/stream_copy.hip
+  // shows the same 5 % on a plain tiled copy)
+  const rigid_f4 v = {a, b, c, d};
+#ifdef MC_RIGID_PLAIN_STORES
+  *reinterpret_cast<rigid_f4*>(p) = v;
+#else
+  __builtin_nontemporal_store(v, reinterpret_cast<rigid_f4*>(p));
+#endif
+}
+
 template <bool WRITE_FRAMES, bool WRITE_SUM, bool FULL, int QUADS>
 __device__ __forceinline__ void rigid_strip_dma(const RigidArgs& a, const float4* wrow, int f,
                                                 int y0, int x0, float wyv,
@@ -674,7 +694,7 @@ __device__ __forceinline__ void rigid_strip_dma(const RigidArgs& a, const float4
         o[k] = rigid_dot5(wy[0], H[(ro + 0) % 5][k], wy[1], H[(ro + 1) % 5][k], wy[2], H[(ro + 2) % 5][k], wy[3],
                           H[(ro + 3) % 5][k], wy[4], H[(ro + 4) % 5][k]);
       if (FULL || (y0 + ro < h && x0 < w)) {
-        if (WRITE_FRAMES) *reinterpret_cast<float4*>(orow + (int64_t)ro * w) = make_float4(o[0], o[1], o[2], o[3]);
+        if (WRITE_FRAMES) rigid_store4(orow + (int64_t)ro * w, o[0], o[1], o[2], o[3]);
         if (WRITE_SUM) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) acc[ro][k] += o[k];
@@ -786,7 +806,14 @@ void warp_rigid_dma(RigidArgs a) {
   __syncthreads();
   if (patch(f_lo, b0)) __syncthreads();
   int cur = 0;
+#ifdef MC_RIGID_STAMP
+  unsigned long long st_c = 0, st_b1 = 0, st_i = 0, st_w = 0, st_b2 = 0;
+#endif
   for (int f = f_lo; f < f_hi; ++f) {
+#ifdef MC_RIGID_STAMP
+    unsigned long long T0, T1, T2, T3, T4, T5;
+    RSTAMP(T0);
+#endif
     if (NBUF == 2 && f + 1 < f_hi) {
       // both kinds of loads for frame f+1 go out BEFORE this frame's stores: the vector-memory
       // counter retires in order, so waiting for "all but the 8 newest" operations below waits for
@@ -797,20 +824,34 @@ void warp_rigid_dma(RigidArgs a) {
     const float4* t = (cur ? b1 : b0) + strip;
     if (full_tile) rigid_strip_dma<WRITE_FRAMES, WRITE_SUM, true, QUADS>(a, t, f, y0, x0, wyv, wx, acc);
     else rigid_strip_dma<WRITE_FRAMES, WRITE_SUM, false, QUADS>(a, t, f, y0, x0, wyv, wx, acc);
+    RSTAMP(T1);
     if (f + 1 < f_hi) {
       if constexpr (NBUF == 1) {
         // single buffer, several workgroups per CU: other workgroups cover this one's latency,
         // so nothing is double-buffered here (registers are the scarce resource)
         __syncthreads();  // everyone must be done reading before the tile is refilled
+        RSTAMP(T2);
         dma(f + 1, b0);
         load_weights(f + 1, wx, wyv);
+        RSTAMP(T3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RSTAMP(T4);
         __syncthreads();
+        RSTAMP(T5);
+#ifdef MC_RIGID_STAMP
+        st_c += T1 - T0; st_b1 += T2 - T1; st_i += T3 - T2; st_w += T4 - T3; st_b2 += T5 - T4;
+#endif
         if (patch(f + 1, b0)) __syncthreads();
       } else {
+        RSTAMP(T2);
         if (WRITE_FRAMES && full_tile) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // RIGID_ROWS stores
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RSTAMP(T4);
         __syncthreads();  // DMA of f+1 landed for every wave; everyone is done with buf[cur]
+        RSTAMP(T5);
+#ifdef MC_RIGID_STAMP
+        st_c += T1 - T0; st_w += T4 - T2; st_b2 += T5 - T4;
+#endif
         cur ^= 1;
         if (patch(f + 1, cur ? b1 : b0)) __syncthreads();
 #pragma unroll
@@ -821,6 +862,12 @@ void warp_rigid_dma(RigidArgs a) {
       }
     }
   }
+#ifdef MC_RIGID_STAMP
+  if (lane == 0) {
+    atomicAdd(&g_rigid_stamps[0], st_c); atomicAdd(&g_rigid_stamps[1], st_b1); atomicAdd(&g_rigid_stamps[2], st_i);
+    atomicAdd(&g_rigid_stamps[3], st_w); atomicAdd(&g_rigid_stamps[4], st_b2); atomicAdd(&g_rigid_stamps[5], 1ull);
+  }
+#endif
   if (WRITE_SUM && x0 < w) {
 #pragma unroll
     for (int ro = 0; ro < RIGID_ROWS; ++ro) {
@@ -839,6 +886,291 @@ void warp_rigid_dma(RigidArgs a) {
     }
   }
 }
+
+#ifdef MC_EXPERIMENTS
+// ------------------------------------------------------------------ rigid warp, loader wave + compute waves
+// EXPERIMENT (built only with -DMC_EXPERIMENTS, selected with MC_RIGID_LS=1; scripts/build_variant.sh).
+// Round 3.  In-kernel stamps of warp_rigid_dma (MC_RIGID_STAMP) showed where a frame step goes: 46 % of
+// a wave's cycles sit in the ISSUE of its LDS-DMA instructions (the vector-memory queue is full, the
+// wave cannot do anything else while it waits for a slot), 14 % in pure arithmetic, 13 % in store
+// back-pressure, the rest in waits and barriers -- and double-buffering inside those waves does not
+// help, because the "asynchronous" DMA blocks the issuing wave all the same.  Here the two jobs are
+// different waves of one workgroup per CU:
+//   * ONE loader wave issues every LDS-DMA of the workgroup, one unit ahead, from per-lane byte offsets
+//     it computed once (73 VGPRs: a loader has nothing else to keep) and a scalar base per unit, so an
+//     interior unit costs it no vector arithmetic at all; it sits in the back-pressured issue so that
+//     nobody else has to, and the CU's read path never runs dry;
+//   * 8 compute waves (2 x 4, 256 columns x 8 rows each) only read LDS, compute and store: reads and
+//     writes flow at the same time, which is what a copy needs to reach the chip's mixed ceiling
+//     (scripts/ubench/stream_copy.hip: 6.2 TB/s for a plain copy against 5.5-5.7 read-only).
+// A tile is 512 x 64 output pixels, processed per frame as two 32-row halves ("units") that alternate
+// between two LDS windows; the four rows the halves share are fetched twice by the same CU within
+// microseconds (an L2 hit), so the y-halo reaching the fabric is 68 / 64 instead of 36 / 32, and the
+// 512 tiles of a 4096^2 frame are exactly two per CU.  One barrier per unit: when it releases, unit
+// u + 1 has landed (the loader waited for its own DMAs) and unit u's window is free for unit u + 2.
+// The weight rows of a frame reach LDS the same way (loaded during the previous frame's second unit,
+// moved to registers at the start of the frame), so the compute waves issue no loads at all.
+// Requires w % 4 == 0 and 16-byte aligned frames (host checks; else warp_rigid_dma / warp_rigid).
+// MEASURED (40 x 4096^2, same box, non-temporal stores in both): bit-identical output; alone 1.039-1.051 ms
+// against 1.054-1.058 for warp_rigid_dma; one loader wave is NOT enough (1.28 ms: vmcnt allows 63 DMAs in
+// flight per wave), two give 1.11, four 1.13.  Stamps: the loader spends 80 % of a unit back-pressured in
+// issue, the compute waves idle half of the time -- the launch is bound by what the memory system gives
+// this access pattern (36 x 2 KB row pieces per window), not by anything a CU does.  Under the two-stream
+// pipeline it LOSES (step 1.78-1.81 against 1.74-1.76 ms): a 10-wave workgroup holding all 160 KB of LDS
+// leaves the estimator's column kernels (32 KB of LDS per workgroup) nowhere to run.  Not the default.
+#define RLS_WX 2
+#define RLS_WY 4
+#define RLS_NC (RLS_WX * RLS_WY)                 // compute waves
+#define RLS_TROWS (RLS_WY * RIGID_ROWS + 4)      // window rows per unit (36)
+#define RLS_Q (RLS_WX * RIGID_LANES + 1)         // float4 columns per window row (129)
+#define RLS_NQ (RLS_TROWS * RLS_Q)               // 4644
+#define RLS_CHUNKS ((RLS_NQ + 63) / 64)          // 73 DMA instructions per unit
+#define RLS_PADQ (RLS_CHUNKS * 64)
+#define RLS_TW (RLS_WX * RIGID_LANES * 4)        // 512
+#define RLS_TH (2 * RLS_WY * RIGID_ROWS)         // 64
+#define RLS_LDS_BYTES ((2 * RLS_PADQ + 5 * RLS_TW / 4) * 16 + RLS_TH * 5 * 4)
+
+template <bool WRITE_FRAMES, bool WRITE_SUM, int NLOAD>
+__global__ __launch_bounds__(RIGID_LANES*(RLS_NC + NLOAD), 3) void warp_rigid_ls(RigidArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_rd[];
+  float4* const buf0 = reinterpret_cast<float4*>(smem_rd);
+  float4* const buf1 = buf0 + RLS_PADQ;
+  float4* const wxs = buf1 + RLS_PADQ;                        // [5][128] quads: Wx[f][j][xt .. xt + 512)
+  float* const wys = reinterpret_cast<float*>(wxs + 5 * RLS_TW / 4);  // [64][5]: Wy[f][yt .. yt + 64)[5]
+  const int nt = a.tiles_x * a.tiles_y;
+  const int b = blockIdx.x;
+  int tile = b;
+  if ((nt & 7) == 0) tile = (b & 7) * (nt >> 3) + (b >> 3);  // one band of tile rows per XCD
+  const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
+  const int h = a.h, w = a.w;
+  const int lane = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int xt = txi * RLS_TW, yt = tyi * RLS_TH;
+  const int64_t hw = (int64_t)h * w;
+  const int nframes = a.nframes;
+
+  if (wave >= RLS_NC) {
+    // ---------------------------------------------------------------- loader wave(s): chunk i belongs to loader i % NLOAD
+    const int lw = wave - RLS_NC;
+    constexpr int MYCH = (RLS_CHUNKS + NLOAD - 1) / NLOAD;
+    unsigned off[MYCH];  // byte offset of this lane's quad of chunk i from the window's first sample
+#pragma unroll
+    for (int m = 0; m < MYCH; ++m) {
+      int q = (m * NLOAD + lw) * 64 + lane;
+      q = q < RLS_NQ ? q : RLS_NQ - 1;  // tail lanes re-load the last quad into the pad
+      const int tr = q / RLS_Q, qc = q - tr * RLS_Q;
+      off[m] = (unsigned)(tr * w + 4 * qc) * 4u;
+    }
+    auto load_unit = [&](int f, int hf, float4* dst) {
+      const float* fr = a.frames + (int64_t)f * hw;
+      const int Sy = a.S[2 * f], Sx = a.S[2 * f + 1];
+      const int ry = yt + hf * (RLS_TH / 2) + Sy - 1;  // image row of window row 0
+      const int ax = xt + Sx - 1;                       // image column of window column 0
+      const bool interior = ry >= 0 && ry + RLS_TROWS <= h && ax >= 0 && ax + 4 * RLS_Q <= w;
+      if (interior) {
+        const char* ub = reinterpret_cast<const char*>(fr + (int64_t)ry * w + ax);
+#pragma unroll
+        for (int m = 0; m < MYCH; ++m) {
+          const int i = m * NLOAD + lw;
+          if (i >= RLS_CHUNKS) break;
+          // the 32-bit offset is made opaque at the point of use: otherwise its zero-extension is
+          // hoisted out of the frame loop, the table becomes 146 registers and spills (and a reload
+          // in the middle of the DMA stream waits for vmcnt(0))
+          unsigned o = off[m];
+          asm volatile("" : "+v"(o));
+          __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(ub + o), (lds_vptr)(dst + i * 64), 16, 0, 0);
+        }
+        return;
+      }
+      // edge unit: rows clipped to the image (border padding), quads kept whole inside the row; the
+      // quads that had to move are patched element by element below
+#pragma unroll 1
+      for (int i = lw; i < RLS_CHUNKS; i += NLOAD) {
+        int q = i * 64 + lane;
+        q = q < RLS_NQ ? q : RLS_NQ - 1;
+        const int tr = q / RLS_Q, qc = q - tr * RLS_Q;
+        int r = ry + tr;
+        r = r < 0 ? 0 : (r > h - 1 ? h - 1 : r);
+        int c = ax + 4 * qc;
+        c = c < 0 ? 0 : (c > w - 4 ? w - 4 : c);
+        __builtin_amdgcn_global_load_lds(fr + (int64_t)r * w + c, (lds_vptr)(dst + i * 64), 16, 0, 0);
+      }
+      // columns outside the row: [0, nl) and [nr, RLS_Q) quads of every window row hold the wrong
+      // samples; re-fetch their elements at the clipped column (own DMAs: one wave, one vmcnt)
+      int nl = ax < 0 ? (-ax + 3) >> 2 : 0;
+      nl = nl > RLS_Q ? RLS_Q : nl;
+      int nr = w - 4 - ax >= 0 ? ((w - 4 - ax) >> 2) + 1 : 0;
+      nr = nr > RLS_Q ? RLS_Q : (nr < nl ? nl : nr);
+      const int nbad = nl + (RLS_Q - nr);
+      if (nbad == 0) return;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      float* t = reinterpret_cast<float*>(dst);
+      const int per_row = 4 * nbad, items = RLS_TROWS * per_row;
+      for (int it = lane; it < items; it += 64) {
+        const int tr = it / per_row, k = it - tr * per_row;
+        const int bq = k >> 2, e = k & 3;
+        const int qc = bq < nl ? bq : nr + (bq - nl);
+        if (NLOAD > 1 && ((tr * RLS_Q + qc) >> 6) % NLOAD != lw) continue;  // only quads this wave's DMAs wrote
+        int r = ry + tr;
+        r = r < 0 ? 0 : (r > h - 1 ? h - 1 : r);
+        int c = ax + 4 * qc + e;
+        c = c < 0 ? 0 : (c > w - 1 ? w - 1 : c);
+        t[(tr * RLS_Q + qc) * 4 + e] = fr[(int64_t)r * w + c];
+      }
+    };
+    // weight rows: uniform base per (frame, tap) + a 32-bit lane offset (columns past the row end are
+    // clipped: their outputs are never stored)
+    unsigned wxo[RLS_WX], wyo[RLS_TH * 5 / 64];
+#pragma unroll
+    for (int i = 0; i < RLS_WX; ++i) {
+      int c = xt + 4 * (64 * i + lane);
+      c = c > w - 4 ? w - 4 : c;
+      wxo[i] = (unsigned)c * 4u;
+    }
+#pragma unroll
+    for (int i = 0; i < RLS_TH * 5 / 64; ++i) {
+      int idx = yt * 5 + i * 64 + lane;
+      idx = idx > h * 5 - 1 ? h * 5 - 1 : idx;
+      wyo[i] = (unsigned)idx * 4u;
+    }
+    auto load_weights = [&](int f) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const char* base = reinterpret_cast<const char*>(a.Wx + ((int64_t)f * 5 + j) * w);
+#pragma unroll
+        for (int i = 0; i < RLS_WX; ++i) {
+          unsigned o = wxo[i];
+          asm volatile("" : "+v"(o));
+          __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(base + o),
+                                           (lds_vptr)(wxs + j * (RLS_TW / 4) + i * 64), 16, 0, 0);
+        }
+      }
+      const char* base = reinterpret_cast<const char*>(a.Wy + (int64_t)f * 5 * h);
+#pragma unroll
+      for (int i = 0; i < RLS_TH * 5 / 64; ++i) {
+        unsigned o = wyo[i];
+        asm volatile("" : "+v"(o));
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(base + o), (lds_vptr)(wys + i * 64), 4, 0, 0);
+      }
+    };
+    load_unit(0, 0, buf0);
+    if (lw == NLOAD - 1) load_weights(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#ifdef MC_RIGID_STAMP
+    unsigned long long T0, T1, T2, T3, sli = 0, slw = 0, slb = 0;
+#endif
+    for (int f = 0; f < nframes; ++f) {
+      RSTAMP(T0);
+      load_unit(f, 1, buf1);  // under the first half of frame f
+      RSTAMP(T1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      RSTAMP(T2);
+      __syncthreads();
+      RSTAMP(T3);
+#ifdef MC_RIGID_STAMP
+      sli += T1 - T0; slw += T2 - T1; slb += T3 - T2;
+#endif
+      if (f + 1 < nframes) {  // under the second half: the next frame's first window and its weights
+        load_unit(f + 1, 0, buf0);
+        if (lw == NLOAD - 1) load_weights(f + 1);
+        RSTAMP(T1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RSTAMP(T2);
+#ifdef MC_RIGID_STAMP
+        sli += T1 - T3; slw += T2 - T1;
+#endif
+      }
+      __syncthreads();
+#ifdef MC_RIGID_STAMP
+      RSTAMP(T3);
+      slb += T3 - T2;
+#endif
+    }
+#ifdef MC_RIGID_STAMP
+    if (lane == 0) {
+      atomicAdd(&g_rigid_stamps[2], sli); atomicAdd(&g_rigid_stamps[3], slw); atomicAdd(&g_rigid_stamps[4], slb);
+      atomicAdd(&g_rigid_stamps[6], 1ull);
+    }
+#endif
+    return;
+  }
+
+  // ------------------------------------------------------------------ compute waves
+  const int wvx = wave % RLS_WX, wvy = wave / RLS_WX;
+  const int x0 = xt + wvx * (RIGID_LANES * 4) + lane * 4;
+  float acc0[RIGID_ROWS][4], acc1[RIGID_ROWS][4];
+#pragma unroll
+  for (int r = 0; r < RIGID_ROWS; ++r)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc0[r][k] = acc1[r][k] = 0.f;
+  const int ya = yt + wvy * RIGID_ROWS, yb = ya + RLS_TH / 2;
+  const bool full_x = xt + RLS_TW <= w;
+  const bool full_a = full_x && yt + RLS_TH / 2 <= h, full_b = full_x && yt + RLS_TH <= h;
+  const int strip = (wvy * RIGID_ROWS) * RLS_Q + wvx * RIGID_LANES + lane;  // this lane's first quad
+  float wx[5][4];
+#ifdef MC_RIGID_STAMP
+  unsigned long long st_c = 0, st_b = 0;
+#endif
+  __syncthreads();  // first window and the first frame's weights have landed
+  for (int f = 0; f < nframes; ++f) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const float4 t = wxs[j * (RLS_TW / 4) + wvx * RIGID_LANES + lane];
+      wx[j][0] = t.x; wx[j][1] = t.y; wx[j][2] = t.z; wx[j][3] = t.w;
+    }
+    // both halves' row weights now: the loader overwrites them during the second half
+    float wya = 0.f, wyb = 0.f;
+    if (lane < 5 * RIGID_ROWS) {
+      wya = wys[(wvy * RIGID_ROWS) * 5 + lane];
+      wyb = wys[(RLS_TH / 2 + wvy * RIGID_ROWS) * 5 + lane];
+    }
+#ifdef MC_RIGID_STAMP
+    unsigned long long C0, C1, C2, C3, C4;
+#endif
+    RSTAMP(C0);
+    if (full_a) rigid_strip_dma<WRITE_FRAMES, WRITE_SUM, true, RLS_Q>(a, buf0 + strip, f, ya, x0, wya, wx, acc0);
+    else rigid_strip_dma<WRITE_FRAMES, WRITE_SUM, false, RLS_Q>(a, buf0 + strip, f, ya, x0, wya, wx, acc0);
+    RSTAMP(C1);
+    __syncthreads();
+    RSTAMP(C2);
+    if (full_b) rigid_strip_dma<WRITE_FRAMES, WRITE_SUM, true, RLS_Q>(a, buf1 + strip, f, yb, x0, wyb, wx, acc1);
+    else rigid_strip_dma<WRITE_FRAMES, WRITE_SUM, false, RLS_Q>(a, buf1 + strip, f, yb, x0, wyb, wx, acc1);
+    RSTAMP(C3);
+    __syncthreads();
+    RSTAMP(C4);
+#ifdef MC_RIGID_STAMP
+    st_c += (C1 - C0) + (C3 - C2); st_b += (C2 - C1) + (C4 - C3);
+#endif
+  }
+#ifdef MC_RIGID_STAMP
+  if (lane == 0) {
+    atomicAdd(&g_rigid_stamps[0], st_c); atomicAdd(&g_rigid_stamps[1], st_b); atomicAdd(&g_rigid_stamps[5], 1ull);
+  }
+#endif
+  if (WRITE_SUM && x0 < w) {
+    const bool al = (((uintptr_t)a.out_sum) & 15) == 0;  // w % 4 == 0 on this path
+#pragma unroll
+    for (int ro = 0; ro < RIGID_ROWS; ++ro) {
+      if (ya + ro < h) {
+        float* dst = a.out_sum + (int64_t)(ya + ro) * w + x0;
+        if (al) *reinterpret_cast<float4*>(dst) = make_float4(acc0[ro][0], acc0[ro][1], acc0[ro][2], acc0[ro][3]);
+        else
+#pragma unroll
+          for (int k = 0; k < 4; ++k) dst[k] = acc0[ro][k];
+      }
+      if (yb + ro < h) {
+        float* dst = a.out_sum + (int64_t)(yb + ro) * w + x0;
+        if (al) *reinterpret_cast<float4*>(dst) = make_float4(acc1[ro][0], acc1[ro][1], acc1[ro][2], acc1[ro][3]);
+        else
+#pragma unroll
+          for (int k = 0; k < 4; ++k) dst[k] = acc1[ro][k];
+      }
+    }
+  }
+}
+
+#endif  // MC_EXPERIMENTS
 
 // ------------------------------------------------------------------ rigid warp, LDS-DMA, fp16 frames
 // The same kernel for frames stored as fp16 (N2: fp16 storage read natively): the window goes
@@ -2355,7 +2687,7 @@ static int warp_rigid_impl(const void* frames_any, int storage, int nframes, int
   if (storage == MC_STORE_F16 && ((w % 8) != 0 || (((uintptr_t)frames_any) & 15) ||
                                   (out_frames && (((uintptr_t)out_frames) & 15))))
     return MC_ERR_UNSUPPORTED;
-  if (!frames || !shifts_px || !scratch || (!out_frames && !out_sum)) return MC_ERR_ARG;
+  if (!frames || !shifts_px || !scratch || (phase != 1 && !out_frames && !out_sum)) return MC_ERR_ARG;  // phase 1 writes no image
   if (nframes < 1 || h < 2 || w < 2 || (((uintptr_t)scratch) & 15) || phase < 0 || phase > 2) return MC_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   float* Wy = scratch;
@@ -2416,6 +2748,55 @@ static int warp_rigid_impl(const void* frames_any, int storage, int nframes, int
 #undef MC_RDH_GO
     return mc_check_launch();
   }
+#ifdef MC_EXPERIMENTS
+  static int use_ls = -1;
+  if (use_ls < 0) {
+    const char* v = getenv("MC_RIGID_LS");
+    use_ls = v ? atoi(v) : 0;
+  }
+  if (dma_ok && use_ls && out_sum && (out_frames || use_ls > 1)) {
+    // fused sum: one loader wave + 8 compute waves per 512 x 64 tile (warp_rigid_ls)
+    a.tiles_x = (w + RLS_TW - 1) / RLS_TW;
+    a.tiles_y = (h + RLS_TH - 1) / RLS_TH;
+    a.frames_in_grid = 0;
+    static int nload = -1;
+    if (nload < 0) {
+      const char* v = getenv("MC_RIGID_NLOAD");
+      nload = v ? atoi(v) : 2;  // one wave's 63 outstanding DMAs (vmcnt) are not enough: 1.28 / 1.11 / 1.13 ms at 1 / 2 / 4
+    }
+    const dim3 gl(a.tiles_x * a.tiles_y), bl(RIGID_LANES, RLS_NC + nload);
+#ifdef MC_RIGID_STAMP
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rigid_stamps), z, sizeof z);
+#endif
+#define MC_RLS_GO(F, NL)                                                                                      \
+  do {                                                                                                        \
+    auto k = warp_rigid_ls<F, true, NL>;                                                                       \
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, RLS_LDS_BYTES);      \
+    hipLaunchKernelGGL(k, gl, bl, RLS_LDS_BYTES, s, a);                                                       \
+  } while (0)
+    if (out_frames) {
+      if (nload == 1) MC_RLS_GO(true, 1);
+      else if (nload == 2) MC_RLS_GO(true, 2);
+      else MC_RLS_GO(true, 4);
+    } else {
+      if (nload == 1) MC_RLS_GO(false, 1);
+      else if (nload == 2) MC_RLS_GO(false, 2);
+      else MC_RLS_GO(false, 4);
+    }
+#undef MC_RLS_GO
+#ifdef MC_RIGID_STAMP
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_rigid_stamps), sizeof z);
+    if (z[5] && z[6]) {
+      const double dc = (double)z[5] * nframes * 2, dl = (double)z[6] * nframes * 2;
+      fprintf(stderr, "rigid_ls stamps (cycles per wave and UNIT): compute+stores %.0f  compute-barrier %.0f | loader: issue %.0f  vmcnt-wait %.0f  barrier %.0f\n",
+              z[0] / dc, z[1] / dc, z[2] / dl, z[3] / dl, z[4] / dl);
+    }
+#endif
+    return mc_check_launch();
+  }
+#endif  // MC_EXPERIMENTS
   if (dma_ok) {
 #define MC_RD_GO(F, S, NB, GX, GY)                                                                  \
   do {                                                                                              \
@@ -2443,9 +2824,22 @@ static int warp_rigid_impl(const void* frames_any, int storage, int nframes, int
     if (nbuf == 1) MC_RD_GEOM(F, S, 1);                        \
     else MC_RD_GEOM(F, S, 2);                                  \
   } while (0)
+#ifdef MC_RIGID_STAMP
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rigid_stamps), z, sizeof z);
+#endif
     if (out_frames && out_sum) MC_RD_LAUNCH(true, true);
     else if (out_frames) MC_RD_LAUNCH(true, false);
     else MC_RD_LAUNCH(false, true);
+#ifdef MC_RIGID_STAMP
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_rigid_stamps), sizeof z);
+    if (z[5]) {
+      const double d = (double)z[5] * (nframes - 1);
+      fprintf(stderr, "rigid stamps (cycles per wave and frame): compute %.0f  barrier1 %.0f  dma-issue %.0f  vmcnt-wait %.0f  barrier2 %.0f  waves %llu frames_out=%d sum=%d\n",
+              z[0] / d, z[1] / d, z[2] / d, z[3] / d, z[4] / d, z[5], out_frames != nullptr, out_sum != nullptr);
+    }
+#endif
 #undef MC_RD_LAUNCH
 #undef MC_RD_GEOM
 #undef MC_RD_GO

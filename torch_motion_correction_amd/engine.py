@@ -469,31 +469,57 @@ def frame_lattices(field, t, grid_type):
 RIGID_KERNEL_HOOK = None  # callable(fn) -> calls fn(); set by bench.py to time warp_rigid_dma alone
 
 
-def warp(img, lattices, pixel_spacing, want_frames=True, want_sum=False, rigid=False):
-    """Resample every frame through its lattice; returns (frames or None, sum or None).
-    rigid=True: the lattices come from a (2,nt,1,1) field, i.e. one shift per frame ->
-    the separable rigid kernel."""
+def rigid_tables(img, lattices, pixel_spacing):
+    """The per-frame weight tables of the rigid warp (rigid_base + rigid_weights: phase 1 of
+    mc_warp_rigid_phase_t) enqueued on the CURRENT stream -> an opaque handle for
+    ``warp(..., rigid=True, tables=handle)``.  The movie pipeline builds them on the estimator's
+    stream, so that the warp stream carries nothing but the resampling launch."""
     lib = _lib.load()
     t, h, w = img.shape
     dev = img.device
-    _, _, GH, GW = lattices.shape
+    shifts_px = (lattices[:, :, 0, 0] / pixel_spacing).contiguous()  # shifts_angstroms / ps
+    nbytes = C.c_int64(0)
+    check(lib.mc_warp_rigid_scratch_bytes(t, h, w, C.byref(nbytes)), "mc_warp_rigid_scratch_bytes")
+    scratch = torch.empty((nbytes.value + 3) // 4, dtype=torch.float32, device=dev)
+    # phase 1 never touches the frames (only their geometry matters): tagged fp32 so that fp16 stacks of
+    # any row length get their tables here, whichever kernel resamples them later
+    check(lib.mc_warp_rigid_phase_t(ptr(img), STORE_F32, t, h, w, ptr(shifts_px), ptr(scratch), None, None, 1,
+                                    stream_ptr(dev)), "mc_warp_rigid_phase")
+    return shifts_px, scratch
+
+
+def warp(img, lattices, pixel_spacing, want_frames=True, want_sum=False, rigid=False, tables=None):
+    """Resample every frame through its lattice; returns (frames or None, sum or None).
+    rigid=True: the lattices come from a (2,nt,1,1) field, i.e. one shift per frame ->
+    the separable rigid kernel (`tables`: the handle of an earlier ``rigid_tables`` call for
+    the same stack and lattices; `lattices` may then be None)."""
+    lib = _lib.load()
+    t, h, w = img.shape
+    dev = img.device
     if rigid and img.dtype == torch.float16 and (w % 8 or img.data_ptr() % 16):
         img = img.float()  # fp16 rows that are not whole 8-sample units: widened once
     frames = torch.empty((t, h, w), dtype=torch.float32, device=dev) if want_frames else None
     total = torch.empty((h, w), dtype=torch.float32, device=dev) if want_sum else None  # the kernels store it
     nbytes = C.c_int64(0)
     if rigid:
-        shifts_px = (lattices[:, :, 0, 0] / pixel_spacing).contiguous()  # shifts_angstroms / ps
-        check(lib.mc_warp_rigid_scratch_bytes(t, h, w, C.byref(nbytes)), "mc_warp_rigid_scratch_bytes")
-        scratch = torch.empty((nbytes.value + 3) // 4, dtype=torch.float32, device=dev)
-        args = (ptr(img), storage_of(img), t, h, w, ptr(shifts_px), ptr(scratch), ptr(frames), ptr(total))
-        if RIGID_KERNEL_HOOK is None:
+        if tables is None and RIGID_KERNEL_HOOK is not None:
+            tables = rigid_tables(img, lattices, pixel_spacing)
+        if tables is None:
+            shifts_px = (lattices[:, :, 0, 0] / pixel_spacing).contiguous()  # shifts_angstroms / ps
+            check(lib.mc_warp_rigid_scratch_bytes(t, h, w, C.byref(nbytes)), "mc_warp_rigid_scratch_bytes")
+            scratch = torch.empty((nbytes.value + 3) // 4, dtype=torch.float32, device=dev)
+            args = (ptr(img), storage_of(img), t, h, w, ptr(shifts_px), ptr(scratch), ptr(frames), ptr(total))
             check(lib.mc_warp_rigid_phase_t(*args, 0, stream_ptr(dev)), "mc_warp_rigid")
+            return frames, total
+        shifts_px, scratch = tables
+        args = (ptr(img), storage_of(img), t, h, w, ptr(shifts_px), ptr(scratch), ptr(frames), ptr(total))
+        run = lambda: check(lib.mc_warp_rigid_phase_t(*args, 2, stream_ptr(dev)), "mc_warp_rigid_phase")
+        if RIGID_KERNEL_HOOK is None:
+            run()
         else:  # instrumentation: the hook brackets the resampling kernel alone (bench.py)
-            check(lib.mc_warp_rigid_phase_t(*args, 1, stream_ptr(dev)), "mc_warp_rigid_phase")
-            RIGID_KERNEL_HOOK(lambda: check(lib.mc_warp_rigid_phase_t(*args, 2, stream_ptr(dev)),
-                                            "mc_warp_rigid_phase"))
+            RIGID_KERNEL_HOOK(run)
         return frames, total
+    _, _, GH, GW = lattices.shape
     check(lib.mc_warp_scratch_bytes(t, h, w, GH, GW, C.byref(nbytes)), "mc_warp_scratch_bytes")
     scratch = torch.empty((nbytes.value + 3) // 4, dtype=torch.float32, device=dev)
     rc = lib.mc_warp_frames_t(ptr(img), storage_of(img), t, h, w, ptr(lattices), GH, GW, float(pixel_spacing),
