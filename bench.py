@@ -214,13 +214,25 @@ def main():
         torch.set_num_threads(os.cpu_count() or 1)
         c0 = time.perf_counter()
         ofield = oracle.estimate_global_motion(sample, 1.0)
-        oracle.correct_motion(sample, ofield, 1.0).sum(0)
+        osum = oracle.correct_motion(sample, ofield, 1.0).sum(0)
         cpu_s = time.perf_counter() - c0
+        # parity at the headline frame size (the oracle as the CHECKER, outside every timed region): the HIP
+        # path on the same n frames against what the CPU leg just computed.  Shifts must be equal; the sum
+        # is compared away from the 16-px border ring (samples whose coordinate sits exactly on the frame
+        # edge are a knife-edge of the reference's zero-outside rule)
+        gfield = mc.estimate_global_motion(stack[:n], 1.0)
+        gsum = mc.motion_correct_sum(stack[:n], gfield, 1.0)
+        torch.cuda.synchronize()
+        inner = (slice(16, -16), slice(16, -16))
         cpu = {
             "value": n / cpu_s, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"first {n} frames of the same {h}x{w} stack: oracle estimate_global_motion + "
                       f"correct_motion + sum, {cpu_s:.1f} s",
+            "parity_shifts_equal": bool(torch.equal(gfield.cpu(), ofield)),
+            "parity_rel_err": float((gsum.cpu()[inner] - osum[inner]).abs().max() / osum[inner].abs().max()),
+            "parity_tolerance": 1e-4,
         }
+        del gfield, gsum
 
     # The same steps on the same stacks STORED as fp16 (reported, never the headline value): K1 and the
     # rigid warp read the 16-bit samples as they are (8 instead of 12 compulsory B/pixel/frame)
@@ -272,6 +284,10 @@ def main():
                 "workload": f"{t3}-frame {h3}x{w3} fp32 movie, 1024-px patch estimate "
                             f"({f3.shape[2]}x{f3.shape[3]} patches) + B-spline warp + frame sum",
                 "estimate_ms": 1e3 * est, "correct_sum_ms": 1e3 * cor, "frames_per_s": t3 / (est + cor),
+                # fraction of the 8 TB/s roofline on the flow's algorithmic bytes (sum-only
+                # output: every frame read by the estimator and by the corrector, the sum written once)
+                "frac": (2.0 * 4 + 4.0 / t3) * h3 * w3 * t3 / (est + cor) / 1e9 / HBM_PEAK_GBS,
+                "correct_sum_frac": (4.0 + 4.0 / t3) * h3 * w3 * t3 / cor / 1e9 / HBM_PEAK_GBS,
                 "sum_finite": bool(torch.isfinite(s3).all()),
                 # aligned frames add coherently: 1.0 = the sum's spread is t x the texture's
                 "sum_coherence": float(s3[64:-64, 64:-64].std()) / (t3 * tex_std),
@@ -296,16 +312,14 @@ def main():
         # warp, plain and dose-weighted sum -- one flow, reported next to the C3 numbers
         try:
             torch.cuda.empty_cache()
-            t5, h5, w5, pad = 60, 8184, 11520, 64
-            g5 = torch.Generator(device=dev).manual_seed(5)
-            base5 = torch.randn(h5 + 2 * pad, w5 + 2 * pad, generator=g5, device=dev)
-            dy5 = torch.round(torch.linspace(-6, 8, t5)).long().tolist()
-            dx5 = torch.round(torch.linspace(5, -4, t5)).long().tolist()
-            st5 = torch.empty((t5, h5, w5), dtype=torch.float16, device=dev)
-            for f in range(t5):
-                st5[f] = (base5[pad - dy5[f]: pad - dy5[f] + h5, pad - dx5[f]: pad - dx5[f] + w5]
-                          + torch.randn(h5, w5, generator=g5, device=dev)).half()
-            del base5
+            t5, h5, w5 = 60, 8184, 11520
+            # the same kind of input as C3: one texture seen through a smooth deformation on the 14 x 21
+            # patch lattice, |shift| <= 2 px (a rigid several-pixel drift is not what the patch estimator is
+            # for: its field on such a stack is meaningless and so is the "aligned" sum)
+            st32, tex5 = synth_local_motion_stack(mc, t5, h5, w5, 14, 21, 5, dev)
+            st5 = st32.half()
+            del st32
+            torch.cuda.empty_cache()
             c5t = []
             for _ in range(2):
                 torch.cuda.synchronize()
@@ -326,8 +340,14 @@ def main():
                             f"({f5.shape[2]}x{f5.shape[3]} patches) + B-spline warp + frame sum / dose-weighted sum",
                 "estimate_ms": 1e3 * est5, "correct_sum_ms": 1e3 * cor5, "correct_dose_weighted_sum_ms": 1e3 * dose5,
                 "frames_per_s_plain_sum": t5 / (est5 + cor5), "frames_per_s_dose_weighted": t5 / (est5 + dose5),
+                # 2 h w 2 + h w 4 / 60 = 383.4 MB of algorithmic bytes per frame
+                "frac_plain_sum": (2.0 * 2 + 4.0 / t5) * h5 * w5 * t5 / (est5 + cor5) / 1e9 / HBM_PEAK_GBS,
+                "frac_dose_weighted": (2.0 * 2 + 4.0 / t5) * h5 * w5 * t5 / (est5 + dose5) / 1e9 / HBM_PEAK_GBS,
                 "peak_hbm_GB": torch.cuda.max_memory_allocated() / 1e9,
                 "sums_finite": bool(torch.isfinite(s5).all() and torch.isfinite(d5).all()),
+                "sum_coherence": float(s5[64:-64, 64:-64].std()) / (t5 * tex5),
+                "input": "one texture through a smooth time-dependent deformation (|shift| <= 2 px) + noise, stored as fp16",
+                "max_abs_field_px": float(f5.abs().max()),
             }
             del st5, f5, s5, d5
             torch.cuda.empty_cache()

@@ -105,7 +105,7 @@ __device__ __forceinline__ void frame_offset(int f, int& sy, int& sx) {
 
 // WX x WY waves, 8 output rows per wave.  HALO: window rows = tile rows + 4, window quads = tile quads + 4
 // (as the 5-tap separable resampler needs); HALO = false: exactly the tile (a pure tiled copy).
-template <int WX, int WY, int NBUF, bool INBLOCK, bool HALO, bool NT_LD, bool NT_ST, bool SUM>
+template <int WX, int WY, int NBUF, bool INBLOCK, bool HALO, bool NT_LD, bool NT_ST, bool SUM, int SPREAD = 0>
 __global__ __launch_bounds__(64 * WX * WY, NBUF == 1 ? 4 : 2) void tile_copy(TileArgs a) {
   constexpr int NWAVES = WX * WY;
   constexpr int TROWS = WY * 8 + (HALO ? 4 : 0);
@@ -135,7 +135,11 @@ __global__ __launch_bounds__(64 * WX * WY, NBUF == 1 ? 4 : 2) void tile_copy(Til
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc[r][k] = 0.f;
   }
-  auto dma = [&](int f, f4* dst) {
+  // SPREAD: workgroup `tile` walks the frames starting at frame (SPREAD * tile) % nframes -- what a set of
+  // workgroups that have drifted apart in time looks like to the memory system
+  auto fmap = [&](int f) { return SPREAD ? (f + SPREAD * tile) % a.nframes : f; };
+  auto dma = [&](int fi, f4* dst) {
+    const int f = fmap(fi);
     const float* fr = a.in + (int64_t)f * hw;
     int sy, sx;
     frame_offset(f, sy, sx);
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(64 * WX * WY, NBUF == 1 ? 4 : 2) void tile_copy(Til
   for (int f = f_lo; f < f_hi; ++f) {
     if (NBUF == 2 && f + 1 < f_hi) dma(f + 1, cur ? b0 : b1);
     const f4* t = (cur ? b1 : b0) + strip;
-    float* orow = a.out + (int64_t)f * hw + (int64_t)y0 * w + x0;
+    float* orow = a.out + (int64_t)fmap(f) * hw + (int64_t)y0 * w + x0;
 #pragma unroll
     for (int ro = 0; ro < 8; ++ro) {
       f4 q0 = t[(ro + (HALO ? 2 : 0)) * QUADS];
@@ -197,6 +201,99 @@ __global__ __launch_bounds__(64 * WX * WY, NBUF == 1 ? 4 : 2) void tile_copy(Til
   }
 }
 
+// ---------------------------------------------------------------- paced in-block copy
+// The same in-block tile copy (halo, sum, nt stores, single buffer, 512 x 32 tiles), PERSISTENT: the grid
+// is one round of co-resident workgroups (2 per CU), workgroup b takes tiles b, b + G, ...  LAG > 0: a
+// workgroup does not start frame f before `arrived[round][f - LAG]` says every workgroup of the round has
+// finished frame f - LAG -- a bounded wait (pacing only: no data is exchanged, so no fences; when the
+// budget runs out the workgroup goes on).  Measures what drift between workgroups costs.
+template <int LAG>
+__global__ __launch_bounds__(512, 4) void tile_paced(TileArgs a, unsigned* __restrict__ arrived, int spin_budget, int nap) {
+  constexpr int WX = 2, WY = 4, NWAVES = 8, TROWS = 36, QUADS = 132, NQ = TROWS * QUADS;
+  constexpr int QUADS_PAD = ((NQ + 63) / 64) * 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f4* const b0 = reinterpret_cast<f4*>(smem);
+  const int nt = a.tiles_x * a.tiles_y, G = gridDim.x;
+  const int h = a.h, w = a.w;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wvx = wave % WX, wvy = wave / WX;
+  const int64_t hw = (int64_t)h * w;
+  int round = 0;
+  for (int b = blockIdx.x; b < nt; b += G, ++round) {
+    int tile = b;
+    if ((nt & 7) == 0) tile = (b & 7) * (nt >> 3) + (b >> 3);
+    const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
+    const int xt = txi * (256 * WX), yt = tyi * (8 * WY);
+    const int x0 = xt + wvx * 256 + lane * 4, y0 = yt + wvy * 8;
+    const int ng = (nt - round * G) < G ? (nt - round * G) : G;  // workgroups in this round
+    unsigned* arr = arrived + round * a.nframes;
+    float acc[8][4];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[r][k] = 0.f;
+    auto dma = [&](int f) {
+      const float* fr = a.in + (int64_t)f * hw;
+      int sy, sx;
+      frame_offset(f, sy, sx);
+      const int ax = xt + sx - 1;
+      for (int i = wave; i < QUADS_PAD / 64; i += NWAVES) {
+        int q = i * 64 + lane;
+        q = q < NQ ? q : NQ - 1;
+        const int tr = q / QUADS, qc = q - tr * QUADS;
+        int r = yt + sy - 1 + tr;
+        r = r < 0 ? 0 : (r > h - 1 ? h - 1 : r);
+        int c = ax + 4 * qc;
+        c = c < 0 ? 0 : (c > w - 4 ? w - 4 : c);
+        __builtin_amdgcn_global_load_lds(fr + (int64_t)r * w + c, (lds_vptr)(b0 + i * 64), 16, 0, 0);
+      }
+    };
+    const int strip = (wvy * 8) * QUADS + wvx * 64 + lane;
+    __syncthreads();  // previous tile's readers are done with the window
+    if (LAG == 0 && spin_budget > 0 && round == 0) {  // initial stagger: up to spin_budget x 2 us, hashed by tile
+      const int naps = (int)(((unsigned)tile * 2654435761u) >> 16) % (unsigned)spin_budget;
+      for (int z = 0; z < naps; ++z) __builtin_amdgcn_s_sleep(63);
+    }
+    dma(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int f = 0; f < a.nframes; ++f) {
+      const f4* t = b0 + strip;
+      float* orow = a.out + (int64_t)f * hw + (int64_t)y0 * w + x0;
+#pragma unroll
+      for (int ro = 0; ro < 8; ++ro) {
+        f4 q0 = t[(ro + 2) * QUADS];
+        const f4 q1 = t[(ro + 2) * QUADS + 1];
+        q0 = q0 * 0.5f + q1 * 0.5f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[ro][k] += q0[k];
+        __builtin_nontemporal_store(q0, reinterpret_cast<f4*>(orow + (int64_t)ro * w));
+      }
+      if (f + 1 < a.nframes) {
+        __syncthreads();
+        if (LAG > 0 && threadIdx.x == 0) {
+          __hip_atomic_fetch_add(&arr[f], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (f + 1 - LAG >= 0) {
+            int budget = spin_budget;
+            while (__hip_atomic_load(&arr[f + 1 - LAG], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ng && --budget > 0)
+              for (int z = 0; z < a.tiles_x /*reused: naps per poll*/ * 0 + nap; ++z) __builtin_amdgcn_s_sleep(63);
+          }
+        }
+        if (LAG > 0) __syncthreads();
+        dma(f + 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+    }
+#pragma unroll
+    for (int ro = 0; ro < 8; ++ro) {
+      f4 v = {acc[ro][0], acc[ro][1], acc[ro][2], acc[ro][3]};
+      *reinterpret_cast<f4*>(a.sum + (int64_t)(y0 + ro) * w + x0) = v;
+    }
+  }
+}
+
 static const char* g_filter = nullptr;
 static int g_reps = 10;
 
@@ -225,14 +322,14 @@ static void run(const char* name, double bytes, F launch) {
   fflush(stdout);
 }
 
-template <int WX, int WY, int NBUF, bool INBLOCK, bool HALO, bool NT_LD, bool NT_ST, bool SUM>
+template <int WX, int WY, int NBUF, bool INBLOCK, bool HALO, bool NT_LD, bool NT_ST, bool SUM, int SPREAD = 0>
 static void run_tile(const char* name, TileArgs a, double bytes) {
   constexpr int TROWS = WY * 8 + (HALO ? 4 : 0), QUADS = WX * 64 + (HALO ? 4 : 0);
   constexpr int QUADS_PAD = ((TROWS * QUADS + 63) / 64) * 64;
   const int lds = QUADS_PAD * 16 * NBUF;
   a.tiles_x = a.w / (256 * WX);
   a.tiles_y = a.h / (8 * WY);
-  auto k = tile_copy<WX, WY, NBUF, INBLOCK, HALO, NT_LD, NT_ST, SUM>;
+  auto k = tile_copy<WX, WY, NBUF, INBLOCK, HALO, NT_LD, NT_ST, SUM, SPREAD>;
   CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   dim3 grid(a.tiles_x * a.tiles_y, INBLOCK ? 1 : a.nframes);
   run(name, bytes, [&] { hipLaunchKernelGGL(k, grid, dim3(64 * WX * WY), lds, 0, a); });
@@ -298,6 +395,35 @@ int main(int argc, char** argv) {
   run_tile<2, 4, 1, false, true, false, false, false>("tile 512x32 fmajor halo", a, 2 * B);
   run_tile<2, 4, 1, false, true, false, true, false>("tile 512x32 fmajor halo nt-st", a, 2 * B);
   run_tile<2, 4, 1, false, true, true, true, false>("tile 512x32 fmajor halo nt-ld nt-st", a, 2 * B);
+  run_tile<2, 4, 1, true, true, false, true, true, 1>("tile 512x32 inblock halo +sum nt-st spread1", a, 2 * B);
+  run_tile<2, 4, 1, true, true, false, true, true, 7>("tile 512x32 inblock halo +sum nt-st spread7", a, 2 * B);
+  {
+    unsigned* arrived;
+    CK(hipMalloc(&arrived, 8 * T * sizeof(unsigned)));
+    TileArgs p = a;
+    p.tiles_x = W / 512;
+    p.tiles_y = H / 32;
+    const int lds = ((36 * 132 + 63) / 64) * 64 * 16;
+    auto go = [&](const char* nm, auto k, int G, int budget, int nap = 1) {
+      CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      run(nm, 2 * B, [&] {
+        CK(hipMemsetAsync(arrived, 0, 8 * T * sizeof(unsigned), 0));
+        hipLaunchKernelGGL(k, dim3(G), dim3(512), lds, 0, p, arrived, budget, nap);
+      });
+    };
+    go("paced persistent G512 lag0 (no pacing)", tile_paced<0>, 512, 0);
+    go("paced persistent G512 lag0 stagger<8us", tile_paced<0>, 512, 4);
+    go("paced persistent G512 lag0 stagger<16us", tile_paced<0>, 512, 8);
+    go("paced persistent G512 lag0 stagger<32us", tile_paced<0>, 512, 16);
+    go("paced persistent G512 lag0 stagger<64us", tile_paced<0>, 512, 32);
+    go("paced persistent G512 lag1 nap1", tile_paced<1>, 512, 2000, 1);
+    go("paced persistent G512 lag2 nap1", tile_paced<2>, 512, 2000, 1);
+    go("paced persistent G512 lag2 nap4", tile_paced<2>, 512, 500, 4);
+    go("paced persistent G512 lag3 nap2", tile_paced<3>, 512, 1000, 2);
+    go("paced persistent G512 lag4 nap2", tile_paced<4>, 512, 1000, 2);
+    go("paced persistent G512 lag4 nap8", tile_paced<4>, 512, 250, 8);
+    go("paced persistent G512 lag8 nap8", tile_paced<8>, 512, 250, 8);
+  }
   run_tile<1, 4, 1, true, true, false, false, true>("tile 256x32 inblock halo +sum", a, 2 * B);
   run_tile<4, 2, 1, true, true, false, false, true>("tile 1024x16 inblock halo +sum", a, 2 * B);
   run_tile<2, 8, 1, true, true, false, false, true>("tile 512x64 inblock halo +sum (16 waves)", a, 2 * B);

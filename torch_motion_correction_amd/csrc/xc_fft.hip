@@ -497,7 +497,16 @@ __global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
           const int r8 = r16 + (rr >> 1) * 8;
           for (int j = tj; j < 4 * g.nkx; j += 256) {  // 4 lanes = the 64 bytes of one kx
             const int kx = j >> 2, w = j & 3;
+#ifdef MC_K1_NTST
+            {
+              typedef float f4 __attribute__((ext_vector_type(4)));
+              const float4 pv = parked[w * (WF_SLAB / 2) + kx];
+              const f4 v = {pv.x, pv.y, pv.z, pv.w};
+              __builtin_nontemporal_store(v, reinterpret_cast<f4*>(out + (int64_t)kx * g.ny + r8 + 2 * w));
+            }
+#else
             *reinterpret_cast<float4*>(out + (int64_t)kx * g.ny + r8 + 2 * w) = parked[w * (WF_SLAB / 2) + kx];
+#endif
           }
         }
         __syncthreads();
