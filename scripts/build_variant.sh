@@ -9,7 +9,7 @@ mkdir -p variants/$tag
 base=$(basename $src .hip)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Iinclude -I$pkg/csrc "$@" -c $pkg/csrc/$src -o variants/$tag/$base.o
 objs=""
-for o in plan_stats xc_fft field_post warp local_motion polyphase full_fft; do
+for o in plan_stats xc_fft xcg_fft_p0 xcg_fft_p1 xcg_fft_p2 xcg_fft_p3 field_post warp local_motion polyphase full_fft; do
   if [ $o = $base ]; then objs="$objs variants/$tag/$base.o"; else objs="$objs $pkg/build/$o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o variants/$tag/libmcorr.so

@@ -1424,6 +1424,7 @@ __device__ __forceinline__ float wave_max_f(float v) {
   return v;
 }
 
+#ifdef MC_EXPERIMENTS  // the first LDS-tile kernel (MC_WARP_FIELD=1): superseded by warp_field2 / warp_field3
 template <bool WRITE_FRAMES, bool WRITE_SUM, bool UNIT_PS>
 __global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES, 2) void warp_field(FieldArgs fa) {
   const WarpArgs& a = fa.w;
@@ -1640,6 +1641,7 @@ __global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES, 2) void warp_field(FieldA
     }
   }
 }
+#endif  // MC_EXPERIMENTS
 
 // ------------------------------------------------------------------ general warp, second version
 // Same tiling, window DMA and per-pixel chain as warp_field, rebuilt around what limits it -- VALU
@@ -2534,12 +2536,7 @@ int mc_warp_frames_t(const void* frames_any, int storage, int nframes, int h, in
   a.ytap = ytap; a.ycoef = ycoef; a.pixel_spacing = pixel_spacing;
   a.out_frames = out_frames; a.out_sum = out_sum;
   const bool unit = (pixel_spacing == 1.0f);
-  static int use_tile = -1;
-  if (use_tile < 0) {
-    const char* v = getenv("MC_WARP_TILE");
-    use_tile = v ? atoi(v) : 1;
-  }
-  if (use_tile && (w % 4 == 0) && ((((uintptr_t)frames) & 15) == 0)) {
+  if ((w % 4 == 0) && ((((uintptr_t)frames) & 15) == 0)) {
     a.tiles_x = (w + RIGID_LANES * 4 - 1) / (RIGID_LANES * 4);
     a.tiles_y = (h + RIGID_WAVES * RIGID_ROWS - 1) / (RIGID_WAVES * RIGID_ROWS);
     FieldArgs fa;
@@ -2552,11 +2549,10 @@ int mc_warp_frames_t(const void* frames_any, int storage, int nframes, int h, in
     if (e != hipSuccess) return (int)e;
     dim3 grid(a.tiles_x * a.tiles_y), block(RIGID_LANES, RIGID_WAVES);
     const size_t lds = (size_t)GW_QUADS_PAD * 16;
-    static int field_version = -1;
-    if (field_version < 0) {
-      const char* v = getenv("MC_WARP_FIELD");
-      field_version = v ? atoi(v) : 3;
-    }
+    int field_version = 3;  // 3: warp_field3; dense lattices fall back to warp_field2
+#ifdef MC_EXPERIMENTS
+    if (const char* v = getenv("MC_WARP_FIELD")) field_version = atoi(v);  // 1: the first LDS-tile kernel
+#endif
     // version 3 stages <= GW3_EROWS lattice rows per tile: 32 pixel rows must span <= 1.5 lattice
     // cells (always for the reference's 10 nodes per patch; not for a per-pixel lattice)
     if ((field_version == 3 || half) && (int64_t)32 * (GH - 1) * 2 <= (int64_t)3 * (h - 1)) {
@@ -2593,6 +2589,7 @@ int mc_warp_frames_t(const void* frames_any, int storage, int nframes, int h, in
       return mc_check_launch();
     }
     if (half) return MC_ERR_UNSUPPORTED;
+#ifdef MC_EXPERIMENTS
 #define MC_GW_LAUNCH(F, S)                                                                  \
   do {                                                                                      \
     if (field_version == 1) {  /* (version 3 falls back to 2 for dense lattices) */          \
@@ -2603,6 +2600,13 @@ int mc_warp_frames_t(const void* frames_any, int storage, int nframes, int h, in
       else hipLaunchKernelGGL((warp_field2<F, S, false>), grid, block, lds, s, fa);         \
     }                                                                                       \
   } while (0)
+#else
+#define MC_GW_LAUNCH(F, S)                                                                  \
+  do {                                                                                      \
+    if (unit) hipLaunchKernelGGL((warp_field2<F, S, true>), grid, block, lds, s, fa);       \
+    else hipLaunchKernelGGL((warp_field2<F, S, false>), grid, block, lds, s, fa);           \
+  } while (0)
+#endif
     if (out_frames && out_sum) MC_GW_LAUNCH(true, true);
     else if (out_frames) MC_GW_LAUNCH(true, false);
     else MC_GW_LAUNCH(false, true);
@@ -2611,6 +2615,10 @@ int mc_warp_frames_t(const void* frames_any, int storage, int nframes, int h, in
     else hipLaunchKernelGGL((warp_field_slow<false>), grid, block, 0, s, fa, out_frames ? 1 : 0, out_sum ? 1 : 0);
     return mc_check_launch();
   }
+  // rows that are not whole float4 quads (or an unaligned stack): the first, untiled kernel.  It reads
+  // fp32 only -- an fp16 stack never gets here (its rows are whole 8-sample units, checked above), and
+  // must not: the kernel would read twice the buffer's bytes
+  if (half) return MC_ERR_UNSUPPORTED;
   a.tiles_x = (w + WARP_TX * WARP_PX - 1) / (WARP_TX * WARP_PX);
   a.tiles_y = (h + WARP_TY * WARP_ROWS - 1) / (WARP_TY * WARP_ROWS);
   dim3 grid(a.tiles_x * a.tiles_y), block(WARP_TX, WARP_TY);
@@ -2703,19 +2711,16 @@ static int warp_rigid_impl(const void* frames_any, int storage, int nframes, int
   RigidArgs a;
   a.frames = frames; a.nframes = nframes; a.h = h; a.w = w; a.S = S; a.Wy = Wy; a.Wx = Wx;
   a.out_frames = out_frames; a.out_sum = out_sum;
-  static int use_dma = -1, geom = -1, nbuf = -1;
-  if (use_dma < 0) {
-    const char* v = getenv("MC_RIGID_DMA");
-    use_dma = v ? atoi(v) : 1;
-    v = getenv("MC_RIGID_GEOM");  // "WXxWY" as two digits, e.g. 14 = 256 x 32 tiles, 24 = 512 x 32
-    // default 24: 512 x 32 tiles, 2 workgroups of 8 waves per CU.  The kernel runs at the box's
-    // mixed read+write ceiling (~5 TB/s of L2<->fabric traffic, scripts/mall_probe.py), so its time
-    // is its bytes: the window over-fetch (halo rows x partial 128-byte lines at both ends of every
-    // row piece) is 1.33x for 256 x 32 tiles and 1.23x for 512 x 32 (measured 1.32 -> 1.23 ms)
-    geom = v ? atoi(v) : 24;
-    v = getenv("MC_RIGID_NBUF");
-    nbuf = v ? atoi(v) : 1;  // single buffer: 3-4 workgroups/CU beat 2 double-buffered ones
-  }
+  // 512 x 32 tiles, single-buffered, 2 workgroups of 8 waves per CU.  Other tile shapes and the
+  // double-buffered form exist in -DMC_EXPERIMENTS builds only (MC_RIGID_GEOM = "WXWY" as two digits,
+  // MC_RIGID_NBUF, MC_RIGID_DMA=0; measured in DESIGN.md section 4: none is faster)
+  int use_dma = 1, geom = 24, nbuf = 1;
+#ifdef MC_EXPERIMENTS
+  if (const char* v = getenv("MC_RIGID_DMA")) use_dma = atoi(v);
+  if (const char* v = getenv("MC_RIGID_GEOM")) geom = atoi(v);
+  if (const char* v = getenv("MC_RIGID_NBUF")) nbuf = atoi(v);
+#endif
+  (void)nbuf;
   const bool dma_ok = use_dma && (w % 4 == 0) && ((((uintptr_t)frames) & 15) == 0) &&
                       (!out_frames || ((((uintptr_t)out_frames) & 15) == 0));
   const int WX = dma_ok ? geom / 10 : 1, WY = dma_ok ? geom % 10 : RIGID_WAVES;
@@ -2805,6 +2810,7 @@ static int warp_rigid_impl(const void* frames_any, int storage, int nframes, int
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(k, grid, block, lds, s, a);                                                  \
   } while (0)
+#ifdef MC_EXPERIMENTS
 #define MC_RD_GEOM(F, S, NB)                                   \
   do {                                                         \
     if (geom == 14) MC_RD_GO(F, S, NB, 1, 4);                  \
@@ -2819,11 +2825,18 @@ static int warp_rigid_impl(const void* frames_any, int storage, int nframes, int
     else if (geom == 26) MC_RD_GO(F, S, NB, 2, 6);             \
     else return MC_ERR_UNSUPPORTED;                                   \
   } while (0)
+#else
+#define MC_RD_GEOM(F, S, NB) MC_RD_GO(F, S, NB, 2, 4)  /* 512 x 32 tiles, 2 workgroups of 8 waves per CU */
+#endif
+#ifdef MC_EXPERIMENTS
 #define MC_RD_LAUNCH(F, S)                                     \
   do {                                                         \
     if (nbuf == 1) MC_RD_GEOM(F, S, 1);                        \
     else MC_RD_GEOM(F, S, 2);                                  \
   } while (0)
+#else
+#define MC_RD_LAUNCH(F, S) MC_RD_GEOM(F, S, 1)
+#endif
 #ifdef MC_RIGID_STAMP
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rigid_stamps), z, sizeof z);
