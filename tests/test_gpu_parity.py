@@ -1803,3 +1803,25 @@ def test_row_major_dose_weighted_sum(mc, dev, shape, ps, dose, pre, kv):
     finally:
         engine.DOSE_COLUMN_MAJOR = True
     assert float((got - rowfed).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the test box has one: never run on hardware so far)")
+def test_entry_points_run_on_a_gpu_that_is_not_the_current_one(mc):
+    """libmcorr launches on the CURRENT HIP device; every API entry point switches to the device its
+    tensors live on (_lib.device_scope).  With cuda:0 current, the estimators and the corrector must work
+    on cuda:1 and agree with the same calls on cuda:0 (this contract was only exercised on a
+    one-GPU box)."""
+    stack, dy, dx = drift_stack(6, 256, 256, seed=3)
+    torch.cuda.set_device(0)
+    res = []
+    for d in ("cuda:0", "cuda:1"):
+        s = stack.to(d)
+        f = mc.estimate_global_motion(s, 1.0)
+        c = mc.correct_motion(s, f, 1.0)
+        pf, _ = mc.estimate_motion_cross_correlation_patches(s, 1.0, patch_sidelength=128)
+        lf = mc.estimate_local_motion(s, 1.0, (128, 128), (6, 2, 2), n_iterations=3)
+        assert f.device == s.device and c.device == s.device and pf.device == s.device and lf.device == s.device
+        res.append((f.cpu(), c.cpu(), pf.cpu(), lf.cpu()))
+    assert torch.cuda.current_device() == 0
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

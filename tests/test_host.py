@@ -258,6 +258,37 @@ def test_full_spectrum_and_storage_entry_points_validate_on_the_host():
                                           one, one, None, None) == -2  # int16 frames are not read natively
 
 
+def test_fp16_stacks_never_reach_an_fp32_only_kernel():
+    """fp16 storage is read natively by the LDS-staged kernels only; every other shape must come back as
+    MC_ERR_UNSUPPORTED *before* any launch (the callers then widen once), never fall through to a kernel
+    that would read the 16-bit buffer as fp32 -- twice its bytes.  Checked on the host with
+    pointers that are never dereferenced: rows that are not whole 8-sample units, an unaligned stack, a
+    dense (per-pixel) lattice; and the rigid warp the same way."""
+    lib = _lib.load()
+    fake = lambda a: ctypes.c_void_p(a)  # noqa: E731  (never dereferenced: the shape checks come first)
+    F16, F32 = 2, 3
+    ok_ptr, odd_ptr = 0x10000, 0x10004
+    cases = [
+        (ok_ptr, 4, 64, 68, 10, 10),    # w % 8 != 0 (but w % 4 == 0: the fp32 tile kernels would take it)
+        (ok_ptr, 4, 64, 66, 10, 10),    # w % 4 != 0: the untiled fp32 kernel's shape
+        (odd_ptr, 4, 64, 64, 10, 10),   # stack not 16-byte aligned
+        (ok_ptr, 4, 64, 64, 64, 64),    # dense lattice: warp_field2's case, fp32 only
+    ]
+    for base, t, h, w, GH, GW in cases:
+        rc = lib.mc_warp_frames_t(fake(base), F16, t, h, w, fake(0x20000), GH, GW, 1.0, fake(0x30000), fake(0x40000),
+                                  None, None)
+        assert rc == -2, (base, t, h, w, GH, GW, rc)
+    # storage tags that no warp reads natively
+    for tag in (0, 1, 7):
+        assert lib.mc_warp_frames_t(fake(ok_ptr), tag, 4, 64, 64, fake(0x20000), 10, 10, 1.0, fake(0x30000),
+                                    fake(0x40000), None, None) == -2
+    for base, w in ((ok_ptr, 68), (odd_ptr, 64)):
+        assert lib.mc_warp_rigid_phase_t(fake(base), F16, 4, 64, w, fake(0x20000), fake(0x30000), fake(0x40000),
+                                         None, 0, None) == -2
+    header = open(os.path.join(ROOT, "include", "mcorr.h")).read()
+    assert "#define MC_STORE_F16 2" in header and "#define MC_STORE_F32 3" in header and F32 == 3
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "torch_motion_correction_amd")
     for fn in os.listdir(pkg):

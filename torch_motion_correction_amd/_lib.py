@@ -130,9 +130,17 @@ def load():
     return lib
 
 
+class McorrUnsupported(McorrError):
+    """An entry point answered MC_ERR_UNSUPPORTED (-2): this shape / storage type has no kernel built in.
+    For fp16 stacks the C side is the single authority on which shapes are read natively; callers catch
+    this, widen the stack once and take the fp32 entry point."""
+
+
 def check(rc: int, what: str):
+    if rc == -2:
+        raise McorrUnsupported(f"{what} failed: unsupported size/mode")
     if rc != 0:
-        kind = {-1: "bad argument", -2: "unsupported size/mode"}.get(rc, f"hipError {rc}")
+        kind = {-1: "bad argument"}.get(rc, f"hipError {rc}")
         raise McorrError(f"{what} failed: {kind}")
 
 

@@ -112,7 +112,7 @@ def _forward_spectra(src, job_off, row_stride, job_expo, pl, stats, use_mask=Tru
     dual = job_expo_b is not None
     wave = _wave512_ok(g, job_expo, use_mask, min_expo)
     if src.dtype != torch.float32 and not wave:
-        raise _lib.McorrError("only the wave-per-row patch kernel reads fp16 frames: widen the stack first")
+        raise _lib.McorrUnsupported("only the wave-per-row patch kernel reads fp16 frames: widen the stack first")
     if dual and not wave:  # no fused kernel for this shape: two ordinary passes
         return (_forward_spectra(src, job_off, row_stride, job_expo, pl, stats, use_mask, use_filter),
                 _forward_spectra(src, job_off, row_stride, job_expo_b, pl, stats, use_mask, use_filter))
@@ -261,10 +261,18 @@ def _global_spectra(img, pl):
     out3 = torch.empty(3, dtype=torch.float32, device=dev)
     T1 = torch.empty((t, g.nkx, g.ny, 2), dtype=torch.float32, device=dev)
     S = torch.empty((t, g.nkx, g.nky, 2), dtype=torch.float32, device=dev)
-    check(lib.mc_xc_rows_forward_stats_t(ptr(img), storage_of(img), ptr(job_off), w, ptr(pl.mask), ptr(m0), ptr(T1),
-                                         ptr(pl.tw_row), t, g, hl, hu, wl, wu, ptr(acc), ptr(fix),
-                                         ptr(out3), ptr(_box_chords(pl, hl, hu, wl, wu)), st),
-          "mc_xc_rows_forward_stats")
+    try:
+        check(lib.mc_xc_rows_forward_stats_t(ptr(img), storage_of(img), ptr(job_off), w, ptr(pl.mask), ptr(m0),
+                                             ptr(T1), ptr(pl.tw_row), t, g, hl, hu, wl, wu, ptr(acc), ptr(fix),
+                                             ptr(out3), ptr(_box_chords(pl, hl, hu, wl, wu)), st),
+              "mc_xc_rows_forward_stats")
+    except _lib.McorrUnsupported:
+        # the C side decides which shapes read fp16 natively (row engine, alignment, geometry); the
+        # predicate above is only a shortcut -- on disagreement widen once, as the warps do
+        if img.dtype == torch.float32:
+            raise
+        del T1, S
+        return _global_spectra(img.float(), pl)
     check(lib.mc_xc_cols_forward_fix(ptr(T1), ptr(pl.filt), ptr(S), ptr(pl.tw_col), t, g, ptr(fix),
                                      ptr(mhat), st), "mc_xc_cols_forward_fix")
     return S
@@ -372,7 +380,13 @@ def patch_field(img, stats, pixel_spacing, reference_frame, reference_strategy, 
             if ref_expo.max() > 1 or cur_expo.max() > 0:
                 raise NotImplementedError("unexpected mask schedule")
             off, ex1 = jobs(range(t), [1] * t)
-            U, V = _forward_spectra(img, off, w, ex1, pl, stats, job_expo_b=ex1 * 2, min_expo=1)
+            try:
+                U, V = _forward_spectra(img, off, w, ex1, pl, stats, job_expo_b=ex1 * 2, min_expo=1)
+            except _lib.McorrUnsupported:
+                if img.dtype == torch.float32:
+                    raise
+                img = img.float()  # the C side has no fp16 kernel for this case after all: widen once
+                U, V = _forward_spectra(img, off, w, ex1, pl, stats, job_expo_b=ex1 * 2, min_expo=1)
             sp, si, sr = lattice.leave_one_out_schedule(ref_expo)
             sp, si, sr = _i32(sp, dev), _i32(si, dev), torch.as_tensor(sr, device=dev)
             REF = torch.empty_like(U)
@@ -384,7 +398,13 @@ def patch_field(img, stats, pixel_spacing, reference_frame, reference_strategy, 
         else:
             exl = [int(cur_expo[f]) + 1 for f in processed]
             off, ex = jobs(processed, exl)
-            S_cur = _forward_spectra(img, off, w, ex, pl, stats, min_expo=min(exl))
+            try:
+                S_cur = _forward_spectra(img, off, w, ex, pl, stats, min_expo=min(exl))
+            except _lib.McorrUnsupported:
+                if img.dtype == torch.float32:
+                    raise
+                img = img.float()
+                S_cur = _forward_spectra(img, off, w, ex, pl, stats, min_expo=min(exl))
             exl = [int(ref_read[f]) + 1 for f in processed]
             off, ex = jobs([reference_frame] * nproc, exl)
             S_ref = _forward_spectra(img, off, w, ex, pl, stats, min_expo=min(exl))
