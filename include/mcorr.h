@@ -81,6 +81,17 @@ int mc_xc_rows_forward(const float* src, const int64_t* job_off, int64_t row_str
                        const int* job_expo, const float* mask, const float* mean_rstd, void* T1,
                        const void* tw_row, int njobs, const mc_xc_geom* geom, void* stream);
 
+/* N2, fused conditioning (examples/ttMotion.py:90-121 gain_correct, :180-199 set_frames_mean_zero, done on
+ * the fly by the kernels that read the raw bytes: no conditioned fp32 movie exists).  One pass over a raw
+ * (t,h,w) movie of storage `kind` (MC_STORE_*) and its optional (h,w) gain reference:
+ *   stats[3 f ..] = { sum v, sum_box v, sum_box v^2 },  v = raw * gain,  box = [hl,hu) x [wl,wu) -- the central box of
+ *   normalize_image (utils.py:76-81);   mu[f] = mean of frame f (0 when mean_zero == 0);
+ *   mean_rstd = {mean, 1/std} of the conditioned box values of ALL frames jointly (unbiased, utils.py:82-83);
+ *   sub[f] = mu[f] + mean: what mc_xc_rows_forward_raw subtracts from raw * gain. */
+int mc_raw_movie_stats(const void* raw, int kind, const float* gain, int nframes, int h, int w, int hl, int hu,
+                       int wl, int wu, int mean_zero, double* stats, float* mu, float* sub, float* mean_rstd,
+                       void* stream);
+
 /* Input conditioning of raw detector frames (caller-side steps of the reference's pipeline,
  * examples/ttMotion.py:90-121 gain multiply and :174-199 per-frame mean-zero):
  * out[f] = raw[f] * gain - mean(raw[f] * gain), fp32 out.  kind: storage type of raw, 0 = u8,
@@ -171,6 +182,16 @@ int mc_xc_rows_forward_stats_t(const void* src, int storage, const int64_t* job_
                                const float* mask, const float* m0, void* T1, const void* tw_row,
                                int njobs, const mc_xc_geom* q, int hl, int hu, int wl, int wu,
                                double* acc, float* fix, float* out3, const int* row_chord, void* stream);
+
+/* N2: K1 from the raw bytes of a u8 / i16 movie, conditioned on the fly (no fp32 movie):
+ *   rows of (raw * gain - job_sub[job]) * mean_rstd[1] * mask  ->  T1, as mc_xc_rows_forward writes it.
+ * `gain` has the frames' row pitch (whole-frame jobs); job_sub / mean_rstd come from mc_raw_movie_stats;
+ * follow with mc_xc_cols_forward (no fix-up: the statistics are known before this pass).  4096-column
+ * frames, 16-byte aligned buffers, row_stride % 8 == 0; anything else: MC_ERR_UNSUPPORTED. */
+int mc_xc_rows_forward_raw(const void* raw, int storage, const float* gain, const int64_t* job_off,
+                           int64_t row_stride, const float* mask, const float* job_sub, const float* mean_rstd,
+                           void* T1, const void* tw_row, int njobs, const mc_xc_geom* q, const int* row_chord,
+                           void* stream);
 
 /* K2.  Column FFT of T1, kept ky rows, times filt (or NULL) -> S[j][kx][kyi].
  * estimate_motion_xc.py:78,98 / :340-346. */
@@ -293,6 +314,15 @@ int mc_warp_frames(const float* frames, int nframes, int h, int w, const float* 
 int mc_warp_frames_t(const void* frames, int storage, int nframes, int h, int w, const float* lattice,
                      int GH, int GW, float pixel_spacing, float* scratch, float* out_frames, float* out_sum,
                      void* stream);
+
+/* N2: the rigid warp (correct_motion for a (2,t,1,1) field, correct_motion.py:18-78) fed from the RAW movie:
+ * every sample is conditioned as raw * gain - mu[f] on its way to the resampler (examples/ttMotion.py:90-121,
+ * 180-199), so the result equals mc_warp_rigid on the output of mc_condition_movie without that fp32 movie.
+ * storage: MC_STORE_U8 or MC_STORE_I16; gain (h,w) fp32; mu from mc_raw_movie_stats; scratch / phase as
+ * mc_warp_rigid_phase.  w % 4 == 0 and 16-byte aligned buffers, else MC_ERR_UNSUPPORTED. */
+int mc_warp_rigid_raw(const void* raw, int storage, const float* gain, const float* mu, int nframes, int h, int w,
+                      const float* shifts_px, float* scratch, float* out_frames, float* out_sum, int phase,
+                      void* stream);
 
 /* Rigid special case of mc_warp_frames: a (2,nt,1,1) field gives each frame ONE shift,
  * shifts_px[f] = (sy, sx) in pixels (device).  The coordinate chain is then separable

@@ -1825,3 +1825,99 @@ def test_entry_points_run_on_a_gpu_that_is_not_the_current_one(mc):
     assert torch.cuda.current_device() == 0
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------ N2: conditioning fused into the first read
+
+
+def _raw_drift_movie(t, h, w, dtype, seed, amp, pad=64):
+    """raw detector-like counts of one texture at integer drift offsets + noise, and a gain reference"""
+    g = torch.Generator().manual_seed(seed)
+    base = torch.rand(h + 2 * pad, w + 2 * pad, generator=g) * 40 + 10
+    dy = torch.round(torch.linspace(-amp, amp + 2, t)).long().tolist()
+    dx = torch.round(torch.linspace(amp - 1, -amp, t)).long().tolist()
+    raw = torch.empty((t, h, w), dtype=dtype)
+    for f in range(t):
+        v = base[pad - dy[f]: pad - dy[f] + h, pad - dx[f]: pad - dx[f] + w] + 6 * torch.randn(h, w, generator=g)
+        if dtype == torch.int16:
+            raw[f] = (v * 8 - 100).round().clamp(-32768, 32767).to(dtype)
+        else:
+            raw[f] = v.round().clamp(0, 255).to(dtype)
+    gain = (1.0 + 0.1 * torch.randn(h, w, generator=g)).clamp(0.5, 1.5)
+    return raw, gain, dy, dx
+
+
+def _numpy_condition(raw, gain):
+    """examples/ttMotion.py:90-121 (movie * gain_map) and :180-199 (minus the frame mean), in float64"""
+    x = raw.numpy().astype(np.float64) * gain.numpy().astype(np.float64)
+    return torch.from_numpy((x - x.mean(axis=(1, 2), keepdims=True)).astype(np.float32))
+
+
+@pytest.mark.parametrize("dtype,amp", [(torch.uint8, 5), (torch.int16, 5), (torch.uint8, 30)])
+def test_fused_raw_path_equals_conditioning_then_the_fp32_path_and_the_oracle(mc, dev, dtype, amp):
+    """N2: raw u8 / i16 movie + gain -> shifts + sum (+ frames) with the conditioning done by the kernels
+    that read the raw bytes (mc_raw_movie_stats, mc_xc_rows_forward_raw, mc_warp_rigid_raw; no fp32 movie).
+    Must equal (a) condition_movie -> estimate_global_motion -> motion_correct_sum on the device: shifts
+    exactly, images to 1e-5 of their range (fp32 roundings of  raw * gain - mu  differ in the last bit), and
+    (b) the ORACLE on the example's numpy conditioning: shifts exactly (and equal to the known drift),
+    frames / sum to the north star's 1e-4.  amp 30: the drift leaves the LDS gain cache several times
+    (re-centring) and pushes windows over the frame border (clipped columns of raw and gain)."""
+    t, h, w = 6, 512, 4096
+    raw, gain, dy, dx = _raw_drift_movie(t, h, w, dtype, 11, amp)
+    rd, gd = raw.to(dev), gain.to(dev)
+    field, total, frames = mc.motion_correct_raw(rd, gd, 1.0, return_frames=True)
+    img = mc.condition_movie(rd, gd)
+    fa = mc.estimate_global_motion(img, 1.0)
+    sa, fra = mc.motion_correct_sum(img, fa, 1.0, return_frames=True)
+    assert torch.equal(field, fa)
+    assert rel_err(frames, fra) <= 1e-5 and rel_err(total, sa) <= 1e-5
+    expect = torch.tensor([[dy[f] - dy[t // 2], dx[f] - dx[t // 2]] for f in range(t)], dtype=torch.float32)
+    assert torch.equal(field[:, :, 0, 0].T.cpu(), expect)
+    cond = _numpy_condition(raw, gain)
+    of = oracle.estimate_global_motion(cond, 1.0)
+    assert torch.equal(field.cpu(), of)
+    oc = oracle.correct_motion(cond, of, 1.0)
+    knife = knife_edge_mask(cond, of, 1.0, "catmull_rom")
+    assert_frames_close(frames, oc, knife, max_excluded=0.05)
+    keep = ~knife.any(0)
+    err = ((total.cpu() - oc.sum(0)).abs() * keep).max() / oc.sum(0).abs().max()
+    assert float(err) <= REL
+
+
+def test_raw_movie_statistics_match_a_float64_reference(mc, dev):
+    from torch_motion_correction_amd import engine
+
+    raw, gain, _, _ = _raw_drift_movie(5, 256, 4096, torch.uint8, 2, 3)
+    rm = engine.RawMovie(raw.to(dev), gain.to(dev))
+    x = raw.double() * gain.double()
+    mu = x.mean(dim=(1, 2))
+    assert float((rm.mu.cpu().double() - mu).abs().max()) <= 1e-5 * float(mu.abs().max())
+    c = x - mu[:, None, None]
+    box = c[:, 64:192, 1024:3072]
+    std, mean = torch.std_mean(box)  # unbiased, all frames jointly: normalize_image (utils.py:76-84)
+    mr = rm.mean_rstd.cpu().double()
+    assert abs(float(mr[0]) - float(mean)) <= 1e-5 * float(std) and abs(float(mr[1]) * float(std) - 1.0) <= 1e-5
+    assert float((rm.sub.cpu().double() - (mu + mean)).abs().max()) <= 1e-5 * float(mu.abs().max())
+    # no gain, no mean-zero: the frames as they are
+    rm0 = engine.RawMovie(raw.to(dev), None, mean_zero=False)
+    assert float(rm0.mu.abs().max()) == 0.0
+
+
+def test_fused_raw_path_falls_back_for_other_shapes_and_pipelines_movies(mc, dev):
+    """Frame shapes without a fused kernel take condition_movie + the fp32 path inside motion_correct_raw
+    (same results by construction); RawMoviePipeline over several movies equals one call per movie."""
+    raw, gain, _, _ = _raw_drift_movie(5, 200, 260, torch.uint8, 5, 3)
+    f1, s1 = mc.motion_correct_raw(raw.to(dev), gain.to(dev), 1.0)
+    img = mc.condition_movie(raw.to(dev), gain.to(dev))
+    f2 = mc.estimate_global_motion(img, 1.0)
+    assert torch.equal(f1, f2) and torch.equal(s1, mc.motion_correct_sum(img, f2, 1.0))
+    movies = [_raw_drift_movie(4, 256, 4096, torch.uint8, 20 + i, 4)[0].to(dev) for i in range(3)]
+    g = _raw_drift_movie(4, 256, 4096, torch.uint8, 20, 4)[1].to(dev)
+    pipe = mc.RawMoviePipeline(g, dev, 1.0, return_frames=True)
+    res = pipe.run(movies)
+    torch.cuda.synchronize()
+    for m, r in zip(movies, res):
+        f, s, fr = mc.motion_correct_raw(m, g, 1.0, return_frames=True)
+        assert torch.equal(r.field, f) and torch.equal(r.total, s) and torch.equal(r.frames, fr)
+    with pytest.raises(TypeError):
+        mc.RawMoviePipeline(g, dev, 1.0).run([movies[0].float()])

@@ -289,6 +289,33 @@ def test_fp16_stacks_never_reach_an_fp32_only_kernel():
     assert "#define MC_STORE_F16 2" in header and "#define MC_STORE_F32 3" in header and F32 == 3
 
 
+def test_raw_entry_points_validate_on_the_host():
+    """N2 entry points (mc_raw_movie_stats, mc_xc_rows_forward_raw, mc_warp_rigid_raw) check storage tags,
+    shapes and pointers before any launch."""
+    lib = _lib.load()
+    fake = lambda a: ctypes.c_void_p(a)  # noqa: E731
+    U8, I16, F16, F32 = 0, 1, 2, 3
+    p = [fake(0x10000 * (i + 1)) for i in range(8)]
+    # statistics: box must lie inside the frame; storage tag 0..3
+    assert lib.mc_raw_movie_stats(p[0], U8, p[1], 4, 64, 64, 16, 48, 16, 80, 1, p[2], p[3], p[4], p[5], None) == -1
+    assert lib.mc_raw_movie_stats(p[0], 9, p[1], 4, 64, 64, 16, 48, 16, 48, 1, p[2], p[3], p[4], p[5], None) == -2
+    assert lib.mc_raw_movie_stats(None, U8, p[1], 4, 64, 64, 16, 48, 16, 48, 1, p[2], p[3], p[4], p[5], None) == -1
+    # K1 from raw bytes: u8 / i16 only, 4096-column frames only
+    g4096 = plan.xc_geometry(4096, 4096, 0.1, 16, 8)
+    g512 = plan.xc_geometry(512, 512, 0.1, 16, 8)
+    args = lambda st, g: (p[0], st, p[1], p[2], 4096, p[3], p[4], p[5], p[6], p[7], 2, g, None, None)  # noqa: E731
+    assert lib.mc_xc_rows_forward_raw(*args(F32, g4096)) == -2
+    assert lib.mc_xc_rows_forward_raw(*args(F16, g4096)) == -2
+    assert lib.mc_xc_rows_forward_raw(*args(U8, g512)) == -2
+    assert lib.mc_xc_rows_forward_raw(None, U8, p[1], p[2], 4096, p[3], p[4], p[5], p[6], p[7], 2, g4096, None, None) == -1
+    # rigid warp from raw bytes: rows of whole quads, aligned buffers, at most 256 frames
+    w = lambda st, nf, ww, raw=p[0]: lib.mc_warp_rigid_raw(raw, st, p[1], p[2], nf, 64, ww, p[3], p[4], p[5], None,  # noqa: E731
+                                                           0, None)
+    assert w(F32, 4, 64) == -2 and w(F16, 4, 64) == -2
+    assert w(U8, 4, 66) == -2 and w(U8, 300, 64) == -2 and w(I16, 4, 64, fake(0x10004)) == -2
+    assert lib.mc_warp_rigid_raw(p[0], U8, None, p[2], 4, 64, 64, p[3], p[4], p[5], None, 0, None) == -1
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "torch_motion_correction_amd")
     for fn in os.listdir(pkg):

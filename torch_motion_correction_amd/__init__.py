@@ -18,6 +18,7 @@ from .api import (  # noqa: F401
     evaluate_deformation_field_at_t,
     get_pixel_shifts,
     image_shifts_to_deformation_field,
+    motion_correct_raw,
     motion_correct_sum,
     resample_deformation_field,
 )
@@ -25,7 +26,7 @@ from ._lib import McorrError  # noqa: F401
 from .data_io import read_deformation_field_from_csv, write_deformation_field_to_csv  # noqa: F401
 from .optimization_state import OptimizationState, OptimizationTracker  # noqa: F401
 from .multi_gpu import motion_correct_movies_sharded  # noqa: F401
-from .pipeline import MoviePipeline, MovieResult, motion_correct_movies  # noqa: F401
+from .pipeline import MoviePipeline, MovieResult, RawMoviePipeline, motion_correct_movies  # noqa: F401
 
 __all__ = [
     "correct_motion",
@@ -41,6 +42,7 @@ __all__ = [
     "OptimizationTracker",
     "estimate_motion",
     "motion_correct_sum",
+    "motion_correct_raw",
     "dose_weighted_sum",
     "condition_movie",
     "evaluate_deformation_field_at_t",
@@ -52,6 +54,7 @@ __all__ = [
     "motion_correct_movies",
     "motion_correct_movies_sharded",
     "MoviePipeline",
+    "RawMoviePipeline",
     "MovieResult",
 ]
 __version__ = "0.1.0"

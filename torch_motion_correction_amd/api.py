@@ -23,7 +23,7 @@ import inspect
 import torch
 
 from . import engine
-from ._lib import device_scope, normalize_frame_index, require_gpu
+from ._lib import McorrUnsupported, device_scope, normalize_frame_index, require_gpu
 
 BUG_COMPATIBLE = True
 RIGID_FAST_PATH = True  # (2,nt,1,1) fields use the separable rigid warp kernel
@@ -356,6 +356,39 @@ def condition_movie(movie, gain=None, mean_zero=True, device=None, hot_pixel_thr
     if return_hot_counts:
         return res[0].to(out_dev), res[1].to(out_dev)
     return res.to(out_dev)
+
+
+@_on_gpu
+def motion_correct_raw(movie, gain, pixel_spacing, reference_frame=None, b_factor=500, frequency_range=(300, 10),
+                       grid_type="catmull_rom", mean_zero=True, return_frames=False, device=None):
+    """The reference pipeline's gain_correct -> set_frames_mean_zero -> estimate_global_motion -> correct_motion
+    -> sum (examples/ttMotion.py:90-121, 180-199, 286-398) for a RAW uint8 / int16 movie, with the conditioning
+    fused into the kernels that read the raw bytes: one statistics pass, then the estimator's row transform and
+    the rigid warp compute ``raw * gain - frame mean`` on the fly.  No conditioned fp32 movie is allocated.
+    Returns ``(field (2,t,1,1) Angstrom, sum (h,w)[, frames (t,h,w)])`` -- what ``condition_movie`` followed by
+    ``estimate_global_motion`` and ``motion_correct_sum`` return.  Frame shapes without a fused kernel
+    (anything but 4096-column frames at the moment) take exactly that route, on an fp32 copy."""
+    out_dev = _out_device(movie, device)
+    dev = require_gpu(out_dev)
+    raw = movie.detach().to(dev)
+    t = raw.shape[0]
+    ref = t // 2 if reference_frame is None else int(reference_frame)
+    ps = float(pixel_spacing)
+    try:
+        rm = engine.RawMovie(raw, None if gain is None else gain.to(dev), mean_zero=bool(mean_zero))
+        shifts = engine.global_shifts_raw(rm, ref, ps, float(b_factor), tuple(frequency_range))
+        field = image_shifts_to_deformation_field(shifts, ps)
+        lat = engine.frame_lattices(field.contiguous(), t, grid_type)
+        frames, total = engine.warp_rigid_raw(rm, lat, ps, want_frames=bool(return_frames), want_sum=True)
+    except (McorrUnsupported, TypeError):
+        img = engine.condition_movie(raw, None if gain is None else gain.to(dev), bool(mean_zero))
+        shifts = engine.global_shifts(img, ref, ps, float(b_factor), tuple(frequency_range))
+        field = image_shifts_to_deformation_field(shifts, ps)
+        lat = engine.frame_lattices(field.contiguous(), t, grid_type)
+        frames, total = engine.warp(img, lat, ps, want_frames=bool(return_frames), want_sum=True, rigid=True)
+    if return_frames:
+        return field.to(out_dev), total.to(out_dev), frames.to(out_dev)
+    return field.to(out_dev), total.to(out_dev)
 
 
 @_on_gpu

@@ -289,6 +289,140 @@ __global__ __launch_bounds__(256) void cond_vec_kernel(const void* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------ N2: statistics of a RAW movie
+// The fused raw path (mc_xc_rows_forward_raw, mc_warp_rigid_raw) never materialises the conditioned
+// movie c_f = raw_f * gain - mu_f (examples/ttMotion.py:90-121, 180-199).  One pass over the raw bytes
+// gives everything the estimator and the warp need to condition on the fly:
+//   stats[f] = { sum_all v, sum_box v, sum_box v^2 },  v = raw * gain,  box = normalize_image's central box
+// and raw_stats_finalize turns them into mu_f (the frame means, as mc_condition_movie rounds them), the
+// joint central-box mean and unbiased standard deviation of the CONDITIONED frames (utils.py:76-84:
+// sum_box (v - mu_f) = S_box - n mu_f, sum_box (v - mu_f)^2 = Q_box - 2 mu_f S_box + n mu_f^2, in double) and
+// the per-frame offset sub_f = mu_f + mean that K1 subtracts.  The gain tile of a pixel group is held in
+// registers over COND_FR frames, as in cond_vec_kernel.
+template <int KIND>
+__global__ __launch_bounds__(256) void raw_stats_kernel(const void* __restrict__ raw, const float* __restrict__ gain,
+                                                        int h, int w, int nframes, int hl, int hu, int wl, int wu,
+                                                        double* __restrict__ stats) {
+  const int f0 = blockIdx.y * COND_FR;
+  const int64_t hw = (int64_t)h * w;
+  double sa[COND_FR], sb[COND_FR], qb[COND_FR];
+#pragma unroll
+  for (int ff = 0; ff < COND_FR; ++ff) sa[ff] = sb[ff] = qb[ff] = 0.0;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < hw; i += (int64_t)gridDim.x * 256 * 8) {
+    float g[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g[k] = 1.f;
+    if (gain) {
+      const float4 a = *reinterpret_cast<const float4*>(gain + i), b = *reinterpret_cast<const float4*>(gain + i + 4);
+      g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w; g[4] = b.x; g[5] = b.y; g[6] = b.z; g[7] = b.w;
+    }
+    // w % 8 == 0 (host): the 8 pixels lie in one row; box weights per pixel, the same for every frame
+    const int y = (int)(i / w), x = (int)(i - (int64_t)y * w);
+    float bw[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bw[k] = (y >= hl && y < hu && x + k >= wl && x + k < wu) ? 1.f : 0.f;
+    const bool any_box = y >= hl && y < hu && x + 7 >= wl && x < wu;
+#pragma unroll
+    for (int ff = 0; ff < COND_FR; ++ff) {
+      if (f0 + ff >= nframes) break;
+      float v[8];
+      cond_load8<KIND>(raw, (int64_t)(f0 + ff) * hw + i, v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] *= g[k];
+      sa[ff] += (double)(((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])));
+      if (any_box) {
+        float ps = 0.f, pq = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          ps = __builtin_fmaf(bw[k], v[k], ps);
+          pq = __builtin_fmaf(bw[k] * v[k], v[k], pq);
+        }
+        sb[ff] += (double)ps;
+        qb[ff] += (double)pq;
+      }
+    }
+  }
+  __shared__ double part[COND_FR][3][4];
+#pragma unroll
+  for (int ff = 0; ff < COND_FR; ++ff) {
+    double r0 = sa[ff], r1 = sb[ff], r2 = qb[ff];
+    for (int off = 32; off > 0; off >>= 1) {
+      r0 += __shfl_down(r0, off);
+      r1 += __shfl_down(r1, off);
+      r2 += __shfl_down(r2, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      part[ff][0][threadIdx.x >> 6] = r0;
+      part[ff][1][threadIdx.x >> 6] = r1;
+      part[ff][2][threadIdx.x >> 6] = r2;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < COND_FR * 3) {
+    const int ff = threadIdx.x / 3, c = threadIdx.x - 3 * ff;
+    if (f0 + ff < nframes)
+      atomicAdd(&stats[3 * (f0 + ff) + c], (part[ff][c][0] + part[ff][c][1]) + (part[ff][c][2] + part[ff][c][3]));
+  }
+}
+
+// scalar form for shapes the vector kernel does not take (w % 8 != 0 or unaligned buffers)
+template <int KIND>
+__global__ __launch_bounds__(256) void raw_stats_scalar_kernel(const void* __restrict__ raw,
+                                                               const float* __restrict__ gain, int h, int w, int hl,
+                                                               int hu, int wl, int wu, double* __restrict__ stats) {
+  const int f = blockIdx.y;
+  const int64_t hw = (int64_t)h * w, base = (int64_t)f * hw;
+  double sa = 0.0, sb = 0.0, qb = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (int64_t)gridDim.x * 256) {
+    const float v = cond_load<KIND>(raw, base + i) * (gain ? gain[i] : 1.f);
+    const int y = (int)(i / w), x = (int)(i - (int64_t)y * w);
+    sa += (double)v;
+    if (y >= hl && y < hu && x >= wl && x < wu) {
+      sb += (double)v;
+      qb += (double)v * (double)v;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    sa += __shfl_down(sa, off);
+    sb += __shfl_down(sb, off);
+    qb += __shfl_down(qb, off);
+  }
+  __shared__ double part[3][4];
+  if ((threadIdx.x & 63) == 0) {
+    part[0][threadIdx.x >> 6] = sa;
+    part[1][threadIdx.x >> 6] = sb;
+    part[2][threadIdx.x >> 6] = qb;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3)
+    atomicAdd(&stats[3 * f + threadIdx.x], (part[threadIdx.x][0] + part[threadIdx.x][1]) +
+                                               (part[threadIdx.x][2] + part[threadIdx.x][3]));
+}
+
+// out: mu[t], sub[t] = mu + mean, mean_rstd[0..1] = {mean, 1 / std} of the conditioned central box
+// (all frames jointly, unbiased: torch.std_mean, utils.py:82-83); mean_zero = 0: mu = 0
+__global__ void raw_stats_finalize(const double* __restrict__ stats, int nframes, int64_t hw, int64_t nbox,
+                                   int mean_zero, float* __restrict__ mu, float* __restrict__ sub,
+                                   float* __restrict__ mean_rstd) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double S = 0.0, Q = 0.0;
+  for (int f = 0; f < nframes; ++f) {
+    const float m = mean_zero ? (float)(stats[3 * f] / (double)hw) : 0.f;  // as mc_condition_movie rounds it
+    mu[f] = m;
+    const double md = (double)m, sb = stats[3 * f + 1], qb = stats[3 * f + 2];
+    S += sb - (double)nbox * md;
+    Q += qb - 2.0 * md * sb + (double)nbox * md * md;
+  }
+  const double N = (double)nbox * nframes;
+  const double mean = S / N;
+  double var = (Q - N * mean * mean) / (N - 1.0);
+  var = var > 0.0 ? var : 0.0;
+  const float meanf = (float)mean;
+  mean_rstd[0] = meanf;
+  mean_rstd[1] = (float)(1.0 / sqrt(var));
+  for (int f = 0; f < nframes; ++f) sub[f] = mu[f] + meanf;
+}
+
 // ------------------------------------------------------------------ hot pixels
 // The example pipeline's remove_hot_pixels (examples/ttMotion.py:127-172) sits between the gain
 // multiply and the mean-zero step: per frame, a pixel of v = raw * gain is hot when
@@ -562,6 +696,44 @@ int mc_condition_movie_hot(const void* raw, int kind, const float* gain, int nfr
     default: MC_HOT(3); break;
   }
 #undef MC_HOT
+  return mc_check_launch();
+}
+
+int mc_raw_movie_stats(const void* raw, int kind, const float* gain, int nframes, int h, int w, int hl, int hu,
+                       int wl, int wu, int mean_zero, double* stats, float* mu, float* sub, float* mean_rstd,
+                       void* stream) {
+  if (!raw || !stats || !mu || !sub || !mean_rstd || nframes < 1 || h < 1 || w < 1) return MC_ERR_ARG;
+  if (kind < 0 || kind > 3) return MC_ERR_UNSUPPORTED;
+  if (hl < 0 || hu > h || wl < 0 || wu > w || hl >= hu || wl >= wu) return MC_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t hw = (int64_t)h * w;
+  hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 3 * nframes, st);
+  if (e != hipSuccess) return (int)e;
+  const bool tiled = (w % 8 == 0) && ((reinterpret_cast<uintptr_t>(raw) & (kind == 0 ? 7 : 15)) == 0) &&
+                     (!gain || (reinterpret_cast<uintptr_t>(gain) & 15) == 0);
+  if (tiled) {
+    int64_t tb = (hw / 8 + 255) / 256;
+    if (tb > 2048) tb = 2048;
+    const dim3 grid((unsigned)tb, (nframes + COND_FR - 1) / COND_FR);
+    switch (kind) {
+      case 0: hipLaunchKernelGGL(raw_stats_kernel<0>, grid, dim3(256), 0, st, raw, gain, h, w, nframes, hl, hu, wl, wu, stats); break;
+      case 1: hipLaunchKernelGGL(raw_stats_kernel<1>, grid, dim3(256), 0, st, raw, gain, h, w, nframes, hl, hu, wl, wu, stats); break;
+      case 2: hipLaunchKernelGGL(raw_stats_kernel<2>, grid, dim3(256), 0, st, raw, gain, h, w, nframes, hl, hu, wl, wu, stats); break;
+      default: hipLaunchKernelGGL(raw_stats_kernel<3>, grid, dim3(256), 0, st, raw, gain, h, w, nframes, hl, hu, wl, wu, stats); break;
+    }
+  } else {
+    int64_t blocks = (hw + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 2048) blocks = 2048;
+    const dim3 grid((unsigned)blocks, nframes);
+    switch (kind) {
+      case 0: hipLaunchKernelGGL(raw_stats_scalar_kernel<0>, grid, dim3(256), 0, st, raw, gain, h, w, hl, hu, wl, wu, stats); break;
+      case 1: hipLaunchKernelGGL(raw_stats_scalar_kernel<1>, grid, dim3(256), 0, st, raw, gain, h, w, hl, hu, wl, wu, stats); break;
+      case 2: hipLaunchKernelGGL(raw_stats_scalar_kernel<2>, grid, dim3(256), 0, st, raw, gain, h, w, hl, hu, wl, wu, stats); break;
+      default: hipLaunchKernelGGL(raw_stats_scalar_kernel<3>, grid, dim3(256), 0, st, raw, gain, h, w, hl, hu, wl, wu, stats); break;
+    }
+  }
+  hipLaunchKernelGGL(raw_stats_finalize, dim3(1), dim3(64), 0, st, (const double*)stats, nframes, hw,
+                     (int64_t)(hu - hl) * (wu - wl), mean_zero, mu, sub, mean_rstd);
   return mc_check_launch();
 }
 

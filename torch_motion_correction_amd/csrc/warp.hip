@@ -1362,6 +1362,378 @@ void warp_rigid_dma_h(RigidArgs a) {
     }
   }
 }
+// ------------------------------------------------------------------ rigid warp from RAW frames (N2)
+// The same resampler fed from the raw detector bytes: c = raw * gain - mu_f (gain_correct and
+// set_frames_mean_zero of the reference's pipeline, examples/ttMotion.py:90-121, 180-199) is formed on the
+// way from LDS to the registers, so no conditioned fp32 movie exists and the HBM side of a 40 x 4096^2 u8
+// movie reads 0.8 GB instead of 3.3.
+//  * A tile's input windows of all frames overlap almost entirely (they differ by the integer part of the
+//    drift), so the GAIN values they need stay in LDS for the whole frame loop: a cache of (36 + RR_MY) x
+//    (516 + RR_MX + 4) floats shared by the workgroup, de-interleaved into four planes by column mod 4 so
+//    that a lane's eight values come from eight conflict-free ds_read_b32 whatever the window's offset in
+//    the cache.  It is re-centred when a frame's window leaves it -- every wave meets the same frames in
+//    the same order, so the re-load is a workgroup barrier they all arrive at (never a correctness matter;
+//    once or twice per tile for a drift of +-8 px).
+//  * The raw bytes are so few (3.4 KB per wave and frame for u8) that every WAVE keeps its own 12-row
+//    window, double-buffered for u8: no workgroup barrier in the frame loop at all, the eight waves of a
+//    tile drift apart and cover each other's store and DMA latencies (the barrier-coupled first version
+//    ran at the speed of the fp32 kernel although it reads a quarter of its bytes).  Windows are 16-byte
+//    units DMA'd from the 4-byte aligned column at or left of the window (u8: a multiple of 4 samples,
+//    i16: of 2); the sub-unit offset m is wave-uniform and resolved by v_alignbyte on the three (five)
+//    dwords a lane reads per window row.
+// One workgroup of 8 waves (512 x 32 output pixels) per CU.  Requires w % 4 == 0, 16-byte aligned buffers.
+#define RR_MY 8
+#define RR_MX 8
+#define RR_TROWS (4 * RIGID_ROWS + 4)                   // 36 rows of a tile's window
+#define RR_WROWS (RIGID_ROWS + 4)                       // 12 rows of a wave's window
+#define RR_GR (RR_TROWS + RR_MY)                        // 44 cached gain rows
+#define RR_GQ (2 * RIGID_LANES + 1 + RR_MX / 4 + 1)     // 132 quads per cached row (528 columns)
+#define RR_GAIN_BYTES (RR_GR * 4 * RR_GQ * 4)
+#define RR_PAR_MAX 256                                  // frames whose {Sy, Sx, mu} are kept in LDS
+
+template <int KIND>
+struct RawWin {
+  static constexpr int SB = KIND == 0 ? 1 : 2;                 // bytes per sample
+  static constexpr int UPS = 16 / SB;                          // samples per 16-byte unit
+  static constexpr int AL = 4 / SB;                            // samples per 4 bytes: window start granule
+  static constexpr int NU = (RIGID_LANES * 4 + 4 + AL - 1 + UPS - 1) / UPS;  // units per wave-window row (18 / 34)
+  static constexpr int RSTRIDE = NU * 16;                      // bytes per window row in LDS
+  static constexpr int NUNITS = RR_WROWS * NU;
+  static constexpr int UNITS_PAD = ((NUNITS + 63) / 64) * 64;
+  static constexpr int NBUF = KIND == 0 ? 2 : 1;
+  static constexpr int WAVE_BYTES = NBUF * UNITS_PAD * 16;
+  static constexpr int LDS_BYTES = RR_GAIN_BYTES + 8 * WAVE_BYTES + RR_PAR_MAX * 16;
+};
+
+struct RigidRawArgs {
+  RigidArgs r;        // r.frames = the raw movie
+  const float* gain;  // (h, w)
+  const float* mu;    // [f] frame means (mc_raw_movie_stats), subtracted after the gain multiply
+};
+
+template <int KIND, int RR0>
+__device__ __forceinline__ void rigid_raw_read4(unsigned rawrow, unsigned (&d)[4][5]) {
+  // four window rows of this lane's dwords (3 per row for u8, 5 for i16) by INLINE ASSEMBLY: a ds_read the
+  // compiler can see, from the array an LDS-DMA is in flight to, gets an s_waitcnt vmcnt(0) in front of it
+  // (it cannot tell the two halves of the window array apart) -- which waits for the DMA issued a moment ago
+  // and for every store.  The frame loop waits for exactly the DMA that filled THIS window before the strip.
+  using RW = RawWin<KIND>;
+  constexpr int B = RR0 * RW::RSTRIDE, S = RW::RSTRIDE;
+  if constexpr (KIND == 0) {
+    asm volatile(
+        "ds_read_b32 %0, %12 offset:%13\n\tds_read_b32 %1, %12 offset:%14\n\tds_read_b32 %2, %12 offset:%15\n\t"
+        "ds_read_b32 %3, %12 offset:%16\n\tds_read_b32 %4, %12 offset:%17\n\tds_read_b32 %5, %12 offset:%18\n\t"
+        "ds_read_b32 %6, %12 offset:%19\n\tds_read_b32 %7, %12 offset:%20\n\tds_read_b32 %8, %12 offset:%21\n\t"
+        "ds_read_b32 %9, %12 offset:%22\n\tds_read_b32 %10, %12 offset:%23\n\tds_read_b32 %11, %12 offset:%24\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(d[0][0]), "=&v"(d[0][1]), "=&v"(d[0][2]), "=&v"(d[1][0]), "=&v"(d[1][1]), "=&v"(d[1][2]),
+          "=&v"(d[2][0]), "=&v"(d[2][1]), "=&v"(d[2][2]), "=&v"(d[3][0]), "=&v"(d[3][1]), "=&v"(d[3][2])
+        : "v"(rawrow), "i"(B), "i"(B + 4), "i"(B + 8), "i"(B + S), "i"(B + S + 4), "i"(B + S + 8), "i"(B + 2 * S),
+          "i"(B + 2 * S + 4), "i"(B + 2 * S + 8), "i"(B + 3 * S), "i"(B + 3 * S + 4), "i"(B + 3 * S + 8)
+        : "memory");
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      asm volatile("ds_read_b32 %0, %5 offset:%6\n\tds_read_b32 %1, %5 offset:%7\n\tds_read_b32 %2, %5 offset:%8\n\t"
+                   "ds_read_b32 %3, %5 offset:%9\n\tds_read_b32 %4, %5 offset:%10"
+                   : "=&v"(d[r][0]), "=&v"(d[r][1]), "=&v"(d[r][2]), "=&v"(d[r][3]), "=&v"(d[r][4])
+                   : "v"(rawrow + (unsigned)(B + r * S)), "i"(0), "i"(4), "i"(8), "i"(12), "i"(16)
+                   : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+template <bool WRITE_FRAMES, bool WRITE_SUM, bool FULL, int KIND>
+__device__ __forceinline__ void rigid_strip_raw(const RigidArgs& a, unsigned rawrow, int m, const float* gplane,
+                                                const int (&gofs)[8], float negmu, int f, int y0, int x0, float wyv,
+                                                const float (&wx)[5][4], float (&acc)[RIGID_ROWS][4]) {
+  const int h = a.h, w = a.w;
+  float* orow = WRITE_FRAMES ? a.out_frames + (int64_t)f * h * w + (int64_t)y0 * w + x0 : nullptr;
+  float H[5][4];
+  unsigned d[4][5];
+#pragma unroll
+  for (int rr = 0; rr < RIGID_ROWS + 4; ++rr) {
+    if ((rr & 3) == 0) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (rr == 0) rigid_raw_read4<KIND, 0>(rawrow, d);
+      else if (rr == 4) rigid_raw_read4<KIND, 4>(rawrow, d);
+      else rigid_raw_read4<KIND, 8>(rawrow, d);
+    }
+    float rv[8];
+    if constexpr (KIND == 0) {
+      const unsigned w0 = __builtin_amdgcn_alignbyte(d[rr & 3][1], d[rr & 3][0], m);
+      const unsigned w1 = __builtin_amdgcn_alignbyte(d[rr & 3][2], d[rr & 3][1], m);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        rv[k] = (float)((w0 >> (8 * k)) & 0xffu);
+        rv[4 + k] = (float)((w1 >> (8 * k)) & 0xffu);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned wj = __builtin_amdgcn_alignbyte(d[rr & 3][j + 1], d[rr & 3][j], 2 * m);
+        rv[2 * j] = (float)(short)(wj & 0xffffu);
+        rv[2 * j + 1] = (float)((int)wj >> 16);
+      }
+    }
+    float e[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e[k] = __builtin_fmaf(rv[k], gplane[gofs[k] + rr * (4 * RR_GQ)], negmu);
+    float* Hn = H[rr % 5];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      Hn[k] = rigid_dot5(wx[0][k], e[k], wx[1][k], e[k + 1], wx[2][k], e[k + 2], wx[3][k], e[k + 3], wx[4][k], e[k + 4]);
+    if (rr >= 4) {
+      const int ro = rr - 4;
+      float wy[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+        wy[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wyv), ro * 5 + i));
+      float o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        o[k] = rigid_dot5(wy[0], H[(ro + 0) % 5][k], wy[1], H[(ro + 1) % 5][k], wy[2], H[(ro + 2) % 5][k], wy[3],
+                          H[(ro + 3) % 5][k], wy[4], H[(ro + 4) % 5][k]);
+      if (FULL || (y0 + ro < h && x0 < w)) {
+        if (WRITE_FRAMES) rigid_store4(orow + (int64_t)ro * w, o[0], o[1], o[2], o[3]);
+        if (WRITE_SUM) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[ro][k] += o[k];
+        }
+      }
+    }
+  }
+}
+
+// a wave's LDS hand-off to itself (DS operations of one wave execute in order): compiler fence only
+__device__ __forceinline__ void rr_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool WRITE_FRAMES, bool WRITE_SUM, int KIND>
+__global__ __launch_bounds__(RIGID_LANES * 8, 2) void warp_rigid_raw(RigidRawArgs ra) {
+  using RW = RawWin<KIND>;
+  constexpr int WX = 2, WY = 4, NWAVES = 8, NBUF = RW::NBUF;
+  const RigidArgs& a = ra.r;
+  // THREE separate LDS objects, so that the compiler's alias scopes tell the gain cache and the parameter
+  // table (read in the frame loop) apart from the raw windows (the LDS-DMA destination): reads of the former
+  // then need no vmcnt wait while a window DMA is in flight
+  __shared__ float gplane[RR_GR * 4 * RR_GQ];                               // [RR_GR][4 planes][RR_GQ]
+  __shared__ __attribute__((aligned(16))) char rawwin[8 * RW::WAVE_BYTES];  // per wave: NBUF windows
+  __shared__ int4 s_par[RR_PAR_MAX];                                        // {Sy, Sx, mu} per frame
+  const unsigned char* const raw = reinterpret_cast<const unsigned char*>(a.frames);
+  const int nt = a.tiles_x * a.tiles_y;
+  const int b = blockIdx.x;
+  int tile = b;
+  if ((nt & 7) == 0) tile = (b & 7) * (nt >> 3) + (b >> 3);  // one band of tile rows per XCD
+  const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
+  const int h = a.h, w = a.w;
+  const int lane = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int wvx = wave % WX, wvy = wave / WX;
+  const int tid = wave * RIGID_LANES + lane;
+  const int xt = txi * (RIGID_LANES * 4 * WX), yt = tyi * (WY * RIGID_ROWS);
+  const int xw = xt + wvx * (RIGID_LANES * 4);  // first output column of this wave
+  const int x0 = xw + lane * 4, y0 = yt + wvy * RIGID_ROWS;
+  const int64_t hw = (int64_t)h * w;
+  char* const wb0 = rawwin + wave * RW::WAVE_BYTES;  // this wave's raw window(s)
+  char* const wb1 = NBUF == 2 ? wb0 + RW::UNITS_PAD * 16 : wb0;
+  // Per-frame parameters {Sy, Sx, mu} live in LDS: read from global memory inside the frame loop they
+  // become VECTOR loads (the compiler cannot prove that the frame stores do not alias them), and the
+  // s_waitcnt vmcnt(0) in front of their first use drains every DMA and every store in flight -- the
+  // first version of this kernel ran at the fp32 kernel's speed because of exactly that.
+  for (int i = tid; i < a.nframes && i < RR_PAR_MAX; i += RIGID_LANES * NWAVES)
+    s_par[i] = make_int4(a.S[2 * i], a.S[2 * i + 1], __float_as_int(ra.mu[i]), 0);
+  __syncthreads();
+  auto par = [&](int f) {  // nframes <= RR_PAR_MAX (host): an LDS read, never a (flat) load that waits for vmcnt(0)
+    const int4 p = s_par[f];
+    return make_int4(__builtin_amdgcn_readfirstlane(p.x), __builtin_amdgcn_readfirstlane(p.y),
+                     __builtin_amdgcn_readfirstlane(p.z), 0);
+  };
+  float acc[RIGID_ROWS][4];
+#pragma unroll
+  for (int r = 0; r < RIGID_ROWS; ++r)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[r][k] = 0.f;
+  const bool full_tile = yt + WY * RIGID_ROWS <= h && xt + RIGID_LANES * 4 * WX <= w;
+
+  // the wave's raw window of frame f -> LDS: unit u = (window row, 16 bytes); rows clipped to the image,
+  // units kept whole inside the row (the ones that had to move are patched)
+  auto win_x = [&](int f) { return xw + par(f).y - 1; };   // image column of the WAVE's window column 0
+  auto win_y = [&](int f) { return y0 + par(f).x - 1; };   // image row of the wave's window row 0
+  auto dma = [&](int f, char* dst) {
+    const unsigned char* fr = raw + (int64_t)f * hw * RW::SB;
+    const int wy = win_y(f), axa = win_x(f) & ~(RW::AL - 1);
+#pragma unroll
+    for (int i = 0; i < RW::UNITS_PAD / 64; ++i) {
+      int u = i * 64 + lane;
+      u = u < RW::NUNITS ? u : RW::NUNITS - 1;
+      const int tr = u / RW::NU, uc = u - tr * RW::NU;
+      int r = wy + tr;
+      r = r < 0 ? 0 : (r > h - 1 ? h - 1 : r);
+      int c = axa + RW::UPS * uc;
+      c = c < 0 ? 0 : (c > w - RW::UPS ? w - RW::UPS : c);
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(fr + ((int64_t)r * w + c) * RW::SB),
+                                       (lds_vptr)(dst + (i * 64) * 16), 16, 0, 0);
+    }
+  };
+  auto patch = [&](int f, char* dst) {  // after the wave's vmcnt wait; its own window only
+    const int axa = win_x(f) & ~(RW::AL - 1);
+    if (axa >= 0 && axa + RW::UPS * RW::NU <= w) return;
+    const unsigned char* fr = raw + (int64_t)f * hw * RW::SB;
+    const int wy = win_y(f);
+    int nl = axa < 0 ? (-axa + RW::UPS - 1) / RW::UPS : 0;
+    nl = nl > RW::NU ? RW::NU : nl;
+    int nr = w - RW::UPS - axa >= 0 ? (w - RW::UPS - axa) / RW::UPS + 1 : 0;
+    nr = nr > RW::NU ? RW::NU : (nr < nl ? nl : nr);
+    const int nbad = nl + (RW::NU - nr), per_row = nbad * RW::UPS, items = RR_WROWS * per_row;
+    rr_wave_sync();
+    for (int it = lane; it < items; it += RIGID_LANES) {
+      const int tr = it / per_row, k = it - tr * per_row;
+      const int bu = k / RW::UPS, e = k - bu * RW::UPS;
+      const int uc = bu < nl ? bu : nr + (bu - nl);
+      int r = wy + tr;
+      r = r < 0 ? 0 : (r > h - 1 ? h - 1 : r);
+      int c = axa + RW::UPS * uc + e;
+      c = c < 0 ? 0 : (c > w - 1 ? w - 1 : c);
+      if constexpr (KIND == 0) reinterpret_cast<unsigned char*>(dst)[tr * RW::RSTRIDE + uc * 16 + e] = fr[(int64_t)r * w + c];
+      else reinterpret_cast<unsigned short*>(dst)[tr * (RW::RSTRIDE / 2) + uc * 8 + e] =
+               reinterpret_cast<const unsigned short*>(fr)[(int64_t)r * w + c];
+    }
+    rr_wave_sync();
+  };
+  // gain cache (workgroup): rows [gy0, gy0 + RR_GR) x columns [gx0, gx0 + 4 RR_GQ), gx0 % 4 == 0, border =
+  // clipped index.  Coverage is tested for the TILE's window, so every wave takes the same decision.
+  int gy0 = 0, gx0 = 0;
+  auto tile_x = [&](int f) { return xt + par(f).y - 1; };
+  auto tile_y = [&](int f) { return yt + par(f).x - 1; };
+  auto cache_covers = [&](int f) {
+    const int wy = tile_y(f), ax = tile_x(f);
+    return wy >= gy0 && wy + RR_TROWS <= gy0 + RR_GR && ax >= gx0 && ax + 4 * (2 * RIGID_LANES + 1) <= gx0 + 4 * RR_GQ;
+  };
+  auto cache_load = [&](int f) {
+    gy0 = tile_y(f) - RR_MY / 2;
+    gx0 = (tile_x(f) - RR_MX / 2) & ~3;
+    for (int i = tid; i < RR_GR * RR_GQ; i += RIGID_LANES * NWAVES) {
+      const int gr = i / RR_GQ, gq = i - gr * RR_GQ;
+      int r = gy0 + gr;
+      r = r < 0 ? 0 : (r > h - 1 ? h - 1 : r);
+      const int c = gx0 + 4 * gq;
+      float v[4];
+      if (c >= 0 && c + 3 <= w - 1) {
+        const float4 q = *reinterpret_cast<const float4*>(ra.gain + (int64_t)r * w + c);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          int cc = c + e;
+          cc = cc < 0 ? 0 : (cc > w - 1 ? w - 1 : cc);
+          v[e] = ra.gain[(int64_t)r * w + cc];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gplane[(gr * 4 + e) * RR_GQ + gq] = v[e];
+    }
+  };
+
+  float wx[5][4], wxn[5][4];
+  float wyv = 0.f, wyvn = 0.f;
+  auto load_weights = [&](int f, float (&W5)[5][4], float& Wv) {
+    Wv = 0.f;
+    const int64_t idx = (int64_t)y0 * 5 + lane;
+    if (lane < 5 * RIGID_ROWS && idx < (int64_t)h * 5) Wv = a.Wy[(int64_t)f * 5 * h + idx];
+    const float* Wx = a.Wx + (int64_t)f * 5 * w + x0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (x0 < w) t = *reinterpret_cast<const float4*>(Wx + (int64_t)j * w);
+      W5[j][0] = t.x; W5[j][1] = t.y; W5[j][2] = t.z; W5[j][3] = t.w;
+    }
+  };
+
+  load_weights(0, wx, wyv);
+  dma(0, wb0);
+  cache_load(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  patch(0, wb0);
+  __syncthreads();  // the gain cache is complete
+  int cur = 0;
+#ifdef MC_RIGID_STAMP
+  unsigned long long Q0, Q1, Q2, Q3, Q4, sq_i = 0, sq_p = 0, sq_c = 0, sq_w = 0;
+#endif
+  for (int f = 0; f < a.nframes; ++f) {
+    RSTAMP(Q0);
+    if (NBUF == 2 && f + 1 < a.nframes) {
+      dma(f + 1, cur ? wb0 : wb1);  // lands under this frame's arithmetic
+      load_weights(f + 1, wxn, wyvn);
+    }
+    RSTAMP(Q1);
+    if (!cache_covers(f)) {  // the same frames for every wave of the tile: a rendezvous, then the re-load
+      __syncthreads();       // everyone has finished the frames that used the old position
+      cache_load(f);
+      __syncthreads();
+    }
+    const int ax = win_x(f);
+    const int m = ax & (RW::AL - 1);
+    const int dx = ax - gx0, a4 = dx & 3, q4 = dx >> 2;
+    const int grow = win_y(f) - gy0;
+    int gofs[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) gofs[k] = (grow * 4 + ((a4 + k) & 3)) * RR_GQ + q4 + ((a4 + k) >> 2) + lane;
+    const unsigned rawrow = (unsigned)reinterpret_cast<uintptr_t>((cur ? wb1 : wb0) + lane * 4 * RW::SB);  // LDS byte address
+    const float negmu = -__int_as_float(par(f).z);
+    RSTAMP(Q2);
+    if (full_tile) rigid_strip_raw<WRITE_FRAMES, WRITE_SUM, true, KIND>(a, rawrow, m, gplane, gofs, negmu, f, y0, x0, wyv, wx, acc);
+    else rigid_strip_raw<WRITE_FRAMES, WRITE_SUM, false, KIND>(a, rawrow, m, gplane, gofs, negmu, f, y0, x0, wyv, wx, acc);
+    RSTAMP(Q3);
+    if (f + 1 < a.nframes) {
+      if constexpr (NBUF == 1) {
+        rr_wave_sync();  // this wave's reads of the window are done (in-order DS queue)
+        dma(f + 1, wb0);
+        load_weights(f + 1, wx, wyv);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        patch(f + 1, wb0);
+      } else {
+        if (WRITE_FRAMES && full_tile) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the 8 row stores stay in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        cur ^= 1;
+        patch(f + 1, cur ? wb1 : wb0);
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) wx[j][k] = wxn[j][k];
+        wyv = wyvn;
+      }
+    }
+#ifdef MC_RIGID_STAMP
+    RSTAMP(Q4);
+    sq_i += Q1 - Q0; sq_p += Q2 - Q1; sq_c += Q3 - Q2; sq_w += Q4 - Q3;
+#endif
+  }
+#ifdef MC_RIGID_STAMP
+  if (lane == 0) {
+    atomicAdd(&g_rigid_stamps[0], sq_i); atomicAdd(&g_rigid_stamps[1], sq_p); atomicAdd(&g_rigid_stamps[2], sq_c);
+    atomicAdd(&g_rigid_stamps[3], sq_w); atomicAdd(&g_rigid_stamps[5], 1ull);
+  }
+#endif
+  if (WRITE_SUM && x0 < w) {
+#pragma unroll
+    for (int ro = 0; ro < RIGID_ROWS; ++ro) {
+      const int yo = y0 + ro;
+      if (yo < h) {
+        float* dst = a.out_sum + (int64_t)yo * w + x0;
+        if ((((uintptr_t)a.out_sum) & 15) == 0) {
+          *reinterpret_cast<float4*>(dst) = make_float4(acc[ro][0], acc[ro][1], acc[ro][2], acc[ro][3]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) dst[k] = acc[ro][k];
+        }
+      }
+    }
+  }
+}
 #pragma clang fp contract(off)
 
 // ------------------------------------------------------------------ general warp, LDS tile
@@ -2861,6 +3233,62 @@ static int warp_rigid_impl(const void* frames_any, int storage, int nframes, int
   if (out_frames && out_sum) hipLaunchKernelGGL((warp_rigid<true, true>), grid, block, 0, s, a);
   else if (out_frames) hipLaunchKernelGGL((warp_rigid<true, false>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((warp_rigid<false, true>), grid, block, 0, s, a);
+  return mc_check_launch();
+}
+
+// N2: the rigid warp straight from a raw u8 / i16 movie + gain reference (warp_rigid_raw); phase as in
+// mc_warp_rigid_phase.  Shapes it has no kernel for (w % 4, unaligned buffers): MC_ERR_UNSUPPORTED -- the
+// caller conditions the movie into an fp32 copy first.
+int mc_warp_rigid_raw(const void* raw, int storage, const float* gain, const float* mu, int nframes, int h, int w,
+                      const float* shifts_px, float* scratch, float* out_frames, float* out_sum, int phase,
+                      void* stream) {
+  if (storage != MC_STORE_U8 && storage != MC_STORE_I16) return MC_ERR_UNSUPPORTED;
+  if (!raw || !gain || !mu || !shifts_px || !scratch || (phase != 1 && !out_frames && !out_sum)) return MC_ERR_ARG;
+  if (nframes < 1 || h < 2 || w < 2 || (((uintptr_t)scratch) & 15) || phase < 0 || phase > 2) return MC_ERR_ARG;
+  if ((w % 4) || (((uintptr_t)raw) & 15) || (((uintptr_t)gain) & 15) || (out_frames && (((uintptr_t)out_frames) & 15)) ||
+      w < 16 || nframes > RR_PAR_MAX)
+    return MC_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  float* Wy = scratch;
+  float* Wx = Wy + (int64_t)nframes * 5 * h;
+  int* S = reinterpret_cast<int*>(Wx + (int64_t)nframes * 5 * w);
+  const int n = h > w ? h : w;
+  if (phase != 2) {
+    hipLaunchKernelGGL(rigid_base, dim3(nframes, 2), dim3(256), 0, s, shifts_px, nframes, h, w, S);
+    hipLaunchKernelGGL(rigid_weights, dim3((n + 255) / 256, nframes, 2), dim3(256), 0, s, shifts_px, nframes, h, w, S,
+                       Wy, Wx);
+    if (phase == 1) return mc_check_launch();
+  }
+  RigidRawArgs ra;
+  ra.r.frames = static_cast<const float*>(raw); ra.r.nframes = nframes; ra.r.h = h; ra.r.w = w;
+  ra.r.S = S; ra.r.Wy = Wy; ra.r.Wx = Wx; ra.r.out_frames = out_frames; ra.r.out_sum = out_sum;
+  ra.r.tiles_x = (w + 511) / 512; ra.r.tiles_y = (h + 31) / 32; ra.r.frames_in_grid = 0;
+  ra.gain = gain; ra.mu = mu;
+  const dim3 grid(ra.r.tiles_x * ra.r.tiles_y), block(RIGID_LANES, 8);
+#define MC_RAW_GO(F, SM, K) hipLaunchKernelGGL((warp_rigid_raw<F, SM, K>), grid, block, 0, s, ra) /* static LDS */
+#define MC_RAW_MODE(K)                                     \
+  do {                                                     \
+    if (out_frames && out_sum) MC_RAW_GO(true, true, K);   \
+    else if (out_frames) MC_RAW_GO(true, false, K);        \
+    else MC_RAW_GO(false, true, K);                        \
+  } while (0)
+#ifdef MC_RIGID_STAMP
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rigid_stamps), z, sizeof z);
+#endif
+  if (storage == MC_STORE_U8) MC_RAW_MODE(0);
+  else MC_RAW_MODE(1);
+#ifdef MC_RIGID_STAMP
+  (void)hipStreamSynchronize(s);
+  (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_rigid_stamps), sizeof z);
+  if (z[5]) {
+    const double d = (double)z[5] * nframes;
+    fprintf(stderr, "rigid_raw stamps (cycles per wave and frame): dma+weights issue %.0f  cache/addr %.0f  strip %.0f  wait+copy %.0f\n",
+            z[0] / d, z[1] / d, z[2] / d, z[3] / d);
+  }
+#endif
+#undef MC_RAW_MODE
+#undef MC_RAW_GO
   return mc_check_launch();
 }
 

@@ -189,13 +189,25 @@ __device__ __forceinline__ void wf_pin(int& v, float dep) { asm volatile("" : "+
 // N1LO and N1HI - 1 lie wholly inside the support (host checks) and load unclamped.
 // Statistics: box.wl / box.wu are multiples of 256 (host checks), so a chunk is inside
 // the box or outside it as a whole.
-template <int N1LO, int N1HI, bool CLAMP_ALL, bool HALF = false>
+template <int N1LO, int N1HI, bool CLAMP_ALL, bool HALF = false, int RAW = 0>
 __device__ __forceinline__ void wf_load_px(const void* __restrict__ row_any, int t, int xlo, int xhi,
                                            float4 (&px)[16]) {
-  if constexpr (HALF) {
+  if constexpr (RAW == 1) {
+    // u8 storage (N2): the lane's four samples are ONE dword, kept raw in px[n1].x and widened where the
+    // row is consumed (wf_row), exactly as the fp16 form does
+    const unsigned char* row = static_cast<const unsigned char*>(row_any);
+#pragma unroll
+    for (int n1 = N1LO; n1 < N1HI; ++n1) {
+      const int x = 256 * n1 + 4 * t;
+      const int xs = (CLAMP_ALL || n1 == N1LO || n1 == N1HI - 1) ? min(max(x, xlo), xhi) : x;
+      px[n1].x = __builtin_nontemporal_load(reinterpret_cast<const float*>(row + xs));
+    }
+    return;
+  }
+  if constexpr (HALF || RAW == 2) {
     // fp16 storage: the lane's four samples are 8 bytes; they stay RAW in px[n1].x / .y (converting here
     // would make the prefetch wait for its own loads) and are widened where the row is consumed
-    const _Float16* row = static_cast<const _Float16*>(row_any);
+    const _Float16* row = static_cast<const _Float16*>(row_any);  // (or int16: the same 8 raw bytes)
 #pragma unroll
     for (int n1 = N1LO; n1 < N1HI; ++n1) {
       const int x = 256 * n1 + 4 * t;
@@ -241,7 +253,18 @@ __device__ __forceinline__ wf2 wf_unpack_h2(float bits) {
              (float)__builtin_bit_cast(_Float16, (unsigned short)(v >> 16))};
 }
 
-template <int KEEP, bool STATS, int N1LO, int N1HI, bool CLAMP_ALL, int PREFETCH, bool HALF = false>
+// raw bits of four u8 samples (one dword) / two i16 samples -> floats
+__device__ __forceinline__ void wf_unpack_u8x4(float bits, wf2& a01, wf2& a23) {
+  const unsigned v = __float_as_uint(bits);
+  a01 = wf2{(float)(v & 0xffu), (float)((v >> 8) & 0xffu)};
+  a23 = wf2{(float)((v >> 16) & 0xffu), (float)(v >> 24)};
+}
+__device__ __forceinline__ wf2 wf_unpack_i16x2(float bits) {
+  const unsigned v = __float_as_uint(bits);
+  return wf2{(float)(short)(v & 0xffffu), (float)((int)v >> 16)};
+}
+
+template <int KEEP, bool STATS, int N1LO, int N1HI, bool CLAMP_ALL, int PREFETCH, bool HALF = false, int RAW = 0>
 __device__ __forceinline__ void wf_row(float4 (&px)[16], float4 (&mk)[16],
                                        const void* __restrict__ row, const float* __restrict__ mrow,
                                        const void* __restrict__ next_row,
@@ -249,10 +272,51 @@ __device__ __forceinline__ void wf_row(float4 (&px)[16], float4 (&mk)[16],
                                        const cfloat* twA, const cfloat* twB, const cfloat* twK,
                                        const XcGeom& g, int box_lo, int box_hi, float mean, float rstd,
                                        float& st_s, float& st_q, wf2 (&X)[4][KEEP], int xlo, int xhi,
-                                       int nxlo, int nxhi) {
+                                       int nxlo, int nxhi, const float* __restrict__ grow = nullptr) {
   wf2 A0[16], A1[16];
-  if (PREFETCH < 1) wf_load_px<N1LO, N1HI, CLAMP_ALL, HALF>(row, t, xlo, xhi, px);
-  if (PREFETCH < 2) wf_load_mask<N1LO, N1HI>(mrow, t, mk);
+  if (PREFETCH < 1) wf_load_px<N1LO, N1HI, CLAMP_ALL, HALF, RAW>(row, t, xlo, xhi, px);
+  if constexpr (RAW != 0) {
+    // N2: A = (raw * gain - sub_f) * rstd * mask, `mean` = sub_f = frame mean + box mean (mc_raw_movie_stats).
+    // Gain and mask values are fetched and consumed in two half-row groups: all 32 float4 of a row at
+    // once would be 128 registers next to the 64 of A0 / A1.
+    auto half_row = [&](auto lo_tag) {
+      constexpr int LO = decltype(lo_tag)::value, HI = LO + 8;
+      float4 gq[8], mq[8];
+#pragma unroll
+      for (int n1 = LO; n1 < HI; ++n1) {
+        if (n1 >= N1LO && n1 < N1HI) {
+          const int x = 256 * n1 + 4 * t;
+          const int xs = (CLAMP_ALL || n1 == N1LO || n1 == N1HI - 1) ? min(max(x, xlo), xhi) : x;
+          gq[n1 - LO] = *reinterpret_cast<const float4*>(grow + xs);  // the sample's own (clamped) column
+          mq[n1 - LO] = *reinterpret_cast<const float4*>(mrow + x);
+        }
+      }
+#pragma unroll
+      for (int n1 = LO; n1 < HI; ++n1) {
+        if (n1 >= N1LO && n1 < N1HI) {
+          wf2 r01, r23;
+          if constexpr (RAW == 1) wf_unpack_u8x4(px[n1].x, r01, r23);
+          else { r01 = wf_unpack_i16x2(px[n1].x); r23 = wf_unpack_i16x2(px[n1].y); }
+          const float4 gv = gq[n1 - LO], mv = mq[n1 - LO];
+          const wf2 a01 = __builtin_elementwise_fma(r01, wf2{gv.x, gv.y}, wf2{-mean, -mean});
+          const wf2 a23 = __builtin_elementwise_fma(r23, wf2{gv.z, gv.w}, wf2{-mean, -mean});
+          A0[n1] = (a01 * rstd) * wf2{mv.x, mv.y};
+          A1[n1] = (a23 * rstd) * wf2{mv.z, mv.w};
+        } else {
+          A0[n1] = wf2{0.f, 0.f};
+          A1[n1] = wf2{0.f, 0.f};
+        }
+      }
+    };
+    half_row(std::integral_constant<int, 0>{});
+    {
+      int tp = t;
+      wf_pin(tp, A1[7].y);  // the second group's loads start once the first group has been consumed
+      t = tp;
+    }
+    half_row(std::integral_constant<int, 8>{});
+  }
+  if (PREFETCH < 2 && RAW == 0) wf_load_mask<N1LO, N1HI>(mrow, t, mk);
   auto condition = [&](auto in_box) {
     constexpr bool INBOX = decltype(in_box)::value;
     wf2 acc_s = {0.f, 0.f}, acc_q = {0.f, 0.f};
@@ -280,8 +344,10 @@ __device__ __forceinline__ void wf_row(float4 (&px)[16], float4 (&mk)[16],
       st_q += acc_q.x + acc_q.y;
     }
   };
-  if (STATS && box_hi > box_lo) condition(std::true_type{});  // wave-uniform: a row of the box
-  else condition(std::false_type{});
+  if constexpr (RAW == 0) {
+    if (STATS && box_hi > box_lo) condition(std::true_type{});  // wave-uniform: a row of the box
+    else condition(std::false_type{});
+  }
   int tl = t;  // lane index as the tables see it (re-pinned before each table)
   wf_pin(tl, A0[N1HI - 1].x);
   const WfLane L = wf_lane(tl);  // slab addresses: derived here, not carried across rows
@@ -289,8 +355,8 @@ __device__ __forceinline__ void wf_row(float4 (&px)[16], float4 (&mk)[16],
     if (next_row) {  // issued once this row's samples have been consumed, not earlier
       int tp = t;
       wf_pin(tp, A1[N1HI - 1].y);
-      wf_load_px<N1LO, N1HI, CLAMP_ALL, HALF>(next_row, tp, nxlo, nxhi, px);
-      if (PREFETCH >= 2) wf_load_mask<N1LO, N1HI>(next_mrow, tp, mk);
+      wf_load_px<N1LO, N1HI, CLAMP_ALL, HALF, RAW>(next_row, tp, nxlo, nxhi, px);
+      if (PREFETCH >= 2 && RAW == 0) wf_load_mask<N1LO, N1HI>(next_mrow, tp, mk);
     }
   }
   wf_dft16(A0);
@@ -362,12 +428,16 @@ __device__ __forceinline__ void wf_row(float4 (&px)[16], float4 (&mk)[16],
   wf_unpack_lane<KEEP>(z, wk, L.self != 0, X);
 }
 
-template <int KEEP, bool STATS, int N1LO, int N1HI, bool CLAMP_ALL, int WF_PREFETCH, bool HALF = false>
+// RAW (N2): 1 = u8, 2 = i16 samples conditioned on the fly: `gain` is the (h, row_stride) gain reference
+// (same row pitch as the frames: whole-frame jobs), `job_sub[job]` the per-frame offset, mean_rstd[1]
+// the scale (mc_raw_movie_stats); no statistics are gathered.
+template <int KEEP, bool STATS, int N1LO, int N1HI, bool CLAMP_ALL, int WF_PREFETCH, bool HALF = false, int RAW = 0>
 __global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
     const void* __restrict__ src, const int64_t* __restrict__ job_off, int64_t row_stride,
     const float* __restrict__ mask, const float* __restrict__ mean_rstd, cfloat* __restrict__ T1,
     const cfloat* __restrict__ tw_row, XcGeom g, XcBox box, double* __restrict__ stats_acc,
-    const int2* __restrict__ chord, int lines16) {
+    const int2* __restrict__ chord, int lines16, const float* __restrict__ gain,
+    const float* __restrict__ job_sub) {
   extern __shared__ __attribute__((aligned(16))) float4 park0[];  // lines16: [4 waves][nkx]
   __shared__ __attribute__((aligned(16))) cfloat slabs[4][WF_SLAB];
   __shared__ __attribute__((aligned(16))) cfloat tab[WF_TWA + WF_TWB + 256];
@@ -411,11 +481,12 @@ __global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
       if (i < NTAB) tab[i] = tv[j];
     }
   }
-  const float mean = mean_rstd ? mean_rstd[0] : 0.f;
+  const float mean = RAW ? job_sub[job] : (mean_rstd ? mean_rstd[0] : 0.f);
   const float rstd = mean_rstd ? mean_rstd[1] : 1.f;
-  // frames in their storage type: fp32, or (HALF) fp16 read as it is; job_off / row_stride in samples
-  const char* base = static_cast<const char*>(src) + job_off[job] * (HALF ? 2 : 4);
-  auto row_at = [&](int y) -> const void* { return base + (int64_t)y * row_stride * (HALF ? 2 : 4); };
+  // frames in their storage type: fp32, or (HALF) fp16 / (RAW) u8, i16 read as they are; job_off / row_stride in samples
+  constexpr int SB = RAW == 1 ? 1 : (HALF || RAW == 2) ? 2 : 4;
+  const char* base = static_cast<const char*>(src) + job_off[job] * SB;
+  auto row_at = [&](int y) -> const void* { return base + (int64_t)y * row_stride * SB; };
   float st_s = 0.f, st_q = 0.f;
   cfloat* out = T1 + (int64_t)job * g.nkx * g.ny;
   // A workgroup takes 16 rows in two rounds of 8 consecutive rows; in a round wave wv
@@ -432,9 +503,9 @@ __global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
   auto bounds = [&](int y) { return (CLAMP_ALL && chord) ? chord[y] : make_int2(bxlo, bxhi); };
   if (WF_PREFETCH >= 1 && nrows > 0) {
     const int2 c0 = bounds(g.y0 + row_of(0));
-    wf_load_px<N1LO, N1HI, CLAMP_ALL, HALF>(row_at(g.y0 + row_of(0)), t, c0.x, c0.y, px);
+    wf_load_px<N1LO, N1HI, CLAMP_ALL, HALF, RAW>(row_at(g.y0 + row_of(0)), t, c0.x, c0.y, px);
   }
-  if (WF_PREFETCH >= 2 && nrows > 0)
+  if (WF_PREFETCH >= 2 && RAW == 0 && nrows > 0)
     wf_load_mask<N1LO, N1HI>(mask + (int64_t)(g.y0 + row_of(0)) * g.W, t, mk);
   __syncthreads();
   wf2 Xe[4][KEEP];  // bins of the even row of the current pair
@@ -449,10 +520,10 @@ __global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
     const bool in_box_row = STATS && y >= box.hl && y < box.hu;
     wf2 X[4][KEEP];
     const int2 cb = bounds(y), cn = bounds(rr + 1 < nrows ? yn : y);
-    wf_row<KEEP, STATS, N1LO, N1HI, CLAMP_ALL, WF_PREFETCH, HALF>(px, mk, row, mrow, next_row, next_mrow, t,
-                                                            slab, twA, twB, twK, g, box.wl >> 8,
-                                                            in_box_row ? (box.wu >> 8) : 0, mean, rstd,
-                                                            st_s, st_q, X, cb.x, cb.y, cn.x, cn.y);
+    wf_row<KEEP, STATS, N1LO, N1HI, CLAMP_ALL, WF_PREFETCH, HALF, RAW>(
+        px, mk, row, mrow, next_row, next_mrow, t, slab, twA, twB, twK, g, box.wl >> 8,
+        in_box_row ? (box.wu >> 8) : 0, mean, rstd, st_s, st_q, X, cb.x, cb.y, cn.x, cn.y,
+        RAW ? gain + (int64_t)y * row_stride : nullptr);
     if (rr & 1) {
       int ts = t;
       wf_pin(ts, X[0][0].x);  // addresses: computed here, not carried across rows
@@ -1564,7 +1635,7 @@ static int rows_forward_impl(const float* src, const int64_t* job_off, int64_t r
     if (dyn) (void)hipFuncSetAttribute((const void*)kw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
     hipLaunchKernelGGL(kw, grid, dim3(256), dyn, (hipStream_t)stream, src, job_off, row_stride, mask, \
                        mean_rstd, (cfloat*)T1, (const cfloat*)tw_row, g, b, stats_acc,             \
-                       (const int2*)row_chord, lines16);                                           \
+                       (const int2*)row_chord, lines16, (const float*)nullptr, (const float*)nullptr); \
   } while (0)
 #define MC_WAVE_LAUNCH_H(KEEP, ST)                                                                \
   do {                                                                                            \
@@ -1572,7 +1643,7 @@ static int rows_forward_impl(const float* src, const int64_t* job_off, int64_t r
     if (dyn) (void)hipFuncSetAttribute((const void*)kw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
     hipLaunchKernelGGL(kw, grid, dim3(256), dyn, (hipStream_t)stream, (const void*)src, job_off, row_stride, mask, \
                        mean_rstd, (cfloat*)T1, (const cfloat*)tw_row, g, b, stats_acc,             \
-                       (const int2*)row_chord, lines16);                                           \
+                       (const int2*)row_chord, lines16, (const float*)nullptr, (const float*)nullptr); \
   } while (0)
     if (half) {  // fp16 storage: the general variant (all 16 chunks, per-row chord clamp when given)
       if (g.nkx <= 256) {
@@ -1701,6 +1772,38 @@ int mc_xc_rows_forward_stats_t(const void* src_any, int storage, const int64_t* 
   const double count = (double)njobs * (hu - hl) * (wu - wl);
   hipLaunchKernelGGL(xc_stats_finalize, dim3(1), dim3(1), 0, (hipStream_t)stream, acc, count, m0, fix,
                      out3);
+  return mc_check_launch();
+}
+
+// N2: K1 straight from the raw bytes of a u8 / i16 movie: A = (raw * gain - sub[job]) * mean_rstd[1] * mask.
+// Whole-frame jobs of 4096-column frames (the wave-per-row engine); anything else is MC_ERR_UNSUPPORTED and
+// the caller conditions the movie into an fp32 copy first (mc_condition_movie).
+int mc_xc_rows_forward_raw(const void* raw, int storage, const float* gain, const int64_t* job_off,
+                           int64_t row_stride, const float* mask, const float* job_sub, const float* mean_rstd,
+                           void* T1, const void* tw_row, int njobs, const mc_xc_geom* q, const int* row_chord,
+                           void* stream) {
+  if (storage != MC_STORE_U8 && storage != MC_STORE_I16) return MC_ERR_UNSUPPORTED;
+  XcGeom g;
+  int rc = geom_from(q, &g, true, false);
+  if (rc) return rc;
+  if (!raw || !gain || !job_off || !mask || !job_sub || !mean_rstd || !T1 || !tw_row || njobs < 1) return MC_ERR_ARG;
+  const uintptr_t al = reinterpret_cast<uintptr_t>(raw) | reinterpret_cast<uintptr_t>(gain) |
+                       reinterpret_cast<uintptr_t>(mask);
+  if (!(g.W == 2 * WF_N && g.nkx <= 512 && (g.ny % 8) == 0 && (al & 15) == 0 && (row_stride & 7) == 0))
+    return MC_ERR_UNSUPPORTED;
+  const int ngroups = (g.ny + WF_ROWS_PER_WG - 1) / WF_ROWS_PER_WG;
+  dim3 grid((ngroups + 7) / 8 * 8, njobs);
+  XcBox b{0, 0, 0, 0};
+#define MC_WAVE_RAW(KEEP, R)                                                                                   \
+  hipLaunchKernelGGL((xc_rows_fwd_wave<KEEP, false, 0, 16, true, WF_PREFETCH_DEFAULT, false, R>), grid, dim3(256), 0, \
+                     (hipStream_t)stream, raw, job_off, row_stride, mask, mean_rstd, (cfloat*)T1,               \
+                     (const cfloat*)tw_row, g, b, (double*)nullptr, (const int2*)row_chord, 0, gain, job_sub)
+  if (storage == MC_STORE_U8) {
+    if (g.nkx <= 256) MC_WAVE_RAW(1, 1); else MC_WAVE_RAW(2, 1);
+  } else {
+    if (g.nkx <= 256) MC_WAVE_RAW(1, 2); else MC_WAVE_RAW(2, 2);
+  }
+#undef MC_WAVE_RAW
   return mc_check_launch();
 }
 

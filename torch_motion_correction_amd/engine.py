@@ -311,10 +311,16 @@ def global_shifts(img, reference_frame, pixel_spacing, b_factor, frequency_range
     correlated with itself); anything outside [-t, t) raises IndexError."""
     t, h, w = img.shape
     dev = img.device
-    ref = _lib.normalize_frame_index(reference_frame, t)
-    skip = int(reference_frame) >= 0
     pl = planmod.get_xc_plan(h, w, pixel_spacing, b_factor, frequency_range, dev)
     S = _global_spectra(img, pl)
+    return _shifts_from_spectra(S, t, reference_frame, pl)
+
+
+def _shifts_from_spectra(S, t, reference_frame, pl):
+    """K3 + K4 of the global estimate: every frame's filtered spectrum against the reference frame's."""
+    dev = S.device
+    ref = _lib.normalize_frame_index(reference_frame, t)
+    skip = int(reference_frame) >= 0
     cur = [f for f in range(t) if not (skip and f == ref)]
     if not cur:
         return torch.zeros((t, 2), dtype=torch.float32, device=dev)
@@ -906,6 +912,100 @@ def dose_weighted_sum(img, pixel_spacing, dose_per_frame, pre_exposure=0.0, volt
 
 
 _RAW_KINDS = {torch.uint8: 0, torch.int16: 1, torch.float16: 2, torch.float32: 3}
+
+
+# ------------------------------------------------------------------ N2: the rigid path straight from raw frames
+
+
+class RawMovie:
+    """A raw detector movie with what the fused kernels need to condition it on the fly
+    (c = raw * gain - mu_f, examples/ttMotion.py:90-121, 180-199): the (t,h,w) u8 / i16 stack, the (h,w)
+    fp32 gain reference and, from ONE pass over the raw bytes (mc_raw_movie_stats), the frame means `mu`,
+    the per-frame offsets `sub` = mu + box mean and `mean_rstd` of the conditioned central box.  No fp32
+    movie is ever allocated."""
+
+    def __init__(self, raw, gain, mean_zero=True):
+        lib = _lib.load()
+        if raw.dtype not in (torch.uint8, torch.int16):
+            raise TypeError(f"the fused raw path reads uint8 or int16 frames, got {raw.dtype}")
+        t, h, w = raw.shape
+        dev = raw.device
+        self.raw = raw.contiguous()
+        self.gain = (torch.ones((h, w), dtype=torch.float32, device=dev) if gain is None
+                     else gain.detach().to(device=dev, dtype=torch.float32).contiguous())
+        if tuple(self.gain.shape) != (h, w):
+            raise ValueError(f"gain reference {tuple(self.gain.shape)} does not match the frames {(h, w)}")
+        self.kind = _RAW_KINDS[raw.dtype]
+        self.shape = (t, h, w)
+        hl, hu, wl, wu = int(0.25 * h), int(0.75 * h), int(0.25 * w), int(0.75 * w)  # utils.py:76-81
+        self.stats = torch.empty((t, 3), dtype=torch.float64, device=dev)
+        self.mu = torch.empty(t, dtype=torch.float32, device=dev)
+        self.sub = torch.empty(t, dtype=torch.float32, device=dev)
+        self.mean_rstd = torch.empty(2, dtype=torch.float32, device=dev)
+        check(lib.mc_raw_movie_stats(ptr(self.raw), self.kind, ptr(self.gain), t, h, w, hl, hu, wl, wu,
+                                     1 if mean_zero else 0, ptr(self.stats), ptr(self.mu), ptr(self.sub),
+                                     ptr(self.mean_rstd), stream_ptr(dev)), "mc_raw_movie_stats")
+
+
+def raw_fused_supported(raw, pl):
+    """Shapes the fused raw kernels take (the C side is the authority: anything else answers
+    MC_ERR_UNSUPPORTED and the caller conditions the movie into an fp32 copy)."""
+    t, h, w = raw.shape
+    g = pl.geom
+    return (raw.dtype in (torch.uint8, torch.int16) and w == 4096 and planmod.native_rows(g)
+            and planmod.native_height(g.H) and g.nkx <= 512 and g.ny % 8 == 0 and raw.data_ptr() % 16 == 0)
+
+
+def global_shifts_raw(rm: RawMovie, reference_frame, pixel_spacing, b_factor, frequency_range):
+    """global_shifts for a RawMovie: K1 reads the raw bytes (mc_xc_rows_forward_raw), the statistics are
+    known beforehand, so the column pass needs no fix-up.  Raises McorrUnsupported for shapes without a
+    fused kernel."""
+    lib = _lib.load()
+    t, h, w = rm.shape
+    dev = rm.raw.device
+    _lib.normalize_frame_index(reference_frame, t)  # IndexError before any launch, as the fp32 path
+    pl = planmod.get_xc_plan(h, w, pixel_spacing, b_factor, frequency_range, dev)
+    g = pl.geom
+    if not raw_fused_supported(rm.raw, pl):
+        raise _lib.McorrUnsupported("no fused raw kernel for this frame shape")
+    st = stream_ptr(dev)
+    job_off = _cached(("frame_off", str(dev), t, h, w),
+                      lambda: torch.arange(t, device=dev, dtype=torch.int64) * (h * w))
+    T1 = torch.empty((t, g.nkx, g.ny, 2), dtype=torch.float32, device=dev)
+    S = torch.empty((t, g.nkx, g.nky, 2), dtype=torch.float32, device=dev)
+    check(lib.mc_xc_rows_forward_raw(ptr(rm.raw), rm.kind, ptr(rm.gain), ptr(job_off), w, ptr(pl.mask), ptr(rm.sub),
+                                     ptr(rm.mean_rstd), ptr(T1), ptr(pl.tw_row), t, g,
+                                     ptr(pl.chord) if (pl.chord is not None and USE_ROW_CHORDS) else None, st),
+          "mc_xc_rows_forward_raw")
+    check(lib.mc_xc_cols_forward(ptr(T1), ptr(pl.filt), ptr(S), ptr(pl.tw_col), t, g, st), "mc_xc_cols_forward")
+    del T1
+    return _shifts_from_spectra(S, t, reference_frame, pl)
+
+
+def warp_rigid_raw(rm: RawMovie, lattices, pixel_spacing, want_frames=True, want_sum=False, tables=None):
+    """``warp(..., rigid=True)`` of the conditioned movie without materialising it (mc_warp_rigid_raw)."""
+    lib = _lib.load()
+    t, h, w = rm.shape
+    dev = rm.raw.device
+    frames = torch.empty((t, h, w), dtype=torch.float32, device=dev) if want_frames else None
+    total = torch.empty((h, w), dtype=torch.float32, device=dev) if want_sum else None
+    if tables is None:
+        shifts_px = (lattices[:, :, 0, 0] / pixel_spacing).contiguous()
+        nbytes = C.c_int64(0)
+        check(lib.mc_warp_rigid_scratch_bytes(t, h, w, C.byref(nbytes)), "mc_warp_rigid_scratch_bytes")
+        scratch = torch.empty((nbytes.value + 3) // 4, dtype=torch.float32, device=dev)
+        phase = 0
+    else:
+        shifts_px, scratch = tables
+        phase = 2
+    run = lambda: check(lib.mc_warp_rigid_raw(ptr(rm.raw), rm.kind, ptr(rm.gain), ptr(rm.mu), t, h, w, ptr(shifts_px),
+                                              ptr(scratch), ptr(frames), ptr(total), phase, stream_ptr(dev)),
+                        "mc_warp_rigid_raw")
+    if RIGID_KERNEL_HOOK is not None and phase == 2:
+        RIGID_KERNEL_HOOK(run)
+    else:
+        run()
+    return frames, total
 
 
 def condition_movie(raw, gain=None, mean_zero=True, hot_pixel_threshold=None, return_hot_counts=False):

@@ -113,7 +113,8 @@ class MoviePipeline:
                         self._s_warp.wait_event(ready)
                         field.record_stream(self._s_warp)
                         for x in tables:
-                            x.record_stream(self._s_warp)
+                            if isinstance(x, torch.Tensor):
+                                x.record_stream(self._s_warp)
                         frames, total = call(lambda: self._correct(img, tables))
                 yield MovieResult(field, total, frames)
         finally:
@@ -144,6 +145,51 @@ class MoviePipeline:
         if img.device != self.device or img.dtype != dtype or not img.is_contiguous():
             img = img.detach().to(device=self.device, dtype=dtype).contiguous()
         return img
+
+
+class RawMoviePipeline(MoviePipeline):
+    """The same two-stream pipeline for RAW uint8 / int16 movies and a gain reference (N2): per movie one
+    statistics pass over the raw bytes, then the estimator's row transform and the rigid warp condition the
+    samples on the fly (``raw * gain - frame mean``, examples/ttMotion.py:90-121, 180-199) -- no conditioned
+    fp32 movie is allocated.  Results equal ``condition_movie`` followed by the MoviePipeline.  Frame shapes
+    without a fused kernel raise McorrUnsupported (use ``motion_correct_raw``, which falls back)."""
+
+    def __init__(self, gain, device=None, pixel_spacing: float = 1.0, reference_frame: Optional[int] = None,
+                 b_factor: float = 500, frequency_range=(300, 10), grid_type: str = "catmull_rom",
+                 return_frames: bool = True, overlap: bool = True, mean_zero: bool = True):
+        super().__init__(device, pixel_spacing, reference_frame, b_factor, frequency_range, grid_type,
+                         return_frames, overlap)
+        self.gain = None if gain is None else gain.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        self.mean_zero = bool(mean_zero)
+        self._rm = {}
+
+    def _check(self, img: torch.Tensor) -> torch.Tensor:
+        if img.dim() != 3:
+            raise ValueError(f"expected a (t, h, w) stack, got shape {tuple(img.shape)}")
+        if img.dtype not in (torch.uint8, torch.int16):
+            raise TypeError(f"RawMoviePipeline reads uint8 or int16 movies, got {img.dtype}")
+        if img.device != self.device or not img.is_contiguous():
+            img = img.detach().to(device=self.device).contiguous()
+        return img
+
+    def _estimate(self, img: torch.Tensor) -> torch.Tensor:
+        t = img.shape[0]
+        ref = t // 2 if self.reference_frame is None else int(self.reference_frame)
+        rm = engine.RawMovie(img, self.gain, mean_zero=self.mean_zero)  # the statistics pass, on the estimator's stream
+        self._rm[id(img)] = rm
+        shifts = engine.global_shifts_raw(rm, ref, self.pixel_spacing, self.b_factor, self.frequency_range)
+        return (shifts * self.pixel_spacing).transpose(0, 1)[:, :, None, None]
+
+    def _prepare(self, img: torch.Tensor, field: torch.Tensor):
+        lat = engine.frame_lattices(field.contiguous(), img.shape[0], self.grid_type)
+        rm = self._rm.pop(id(img))
+        shifts_px, scratch = engine.rigid_tables(img, lat, self.pixel_spacing)
+        return shifts_px, scratch, rm.mu, rm
+
+    def _correct(self, img: torch.Tensor, tables):
+        shifts_px, scratch, _, rm = tables
+        return engine.warp_rigid_raw(rm, None, self.pixel_spacing, want_frames=self.return_frames, want_sum=True,
+                                     tables=(shifts_px, scratch))
 
 
 def motion_correct_movies(movies: Iterable[torch.Tensor], pixel_spacing: float, reference_frame=None,
