@@ -260,6 +260,62 @@ def main():
         except Exception as e:
             half_storage = {"error": repr(e)}
 
+    # N2 (reported, never the headline value): the same movies as RAW uint8 detector counts + a gain reference,
+    # through the fused raw pipeline (statistics pass + K1 and the rigid warp conditioning on the fly: no fp32
+    # movie), next to conditioning into an fp32 movie first (mc.condition_movie) and the headline pipeline
+    raw_u8 = None
+    if rank == 0 and world == 1 and not args.no_secondary:
+        try:
+            gq = torch.Generator(device=dev).manual_seed(99)
+            gain = (1.0 + 0.05 * torch.randn(h, w, generator=gq, device=dev)).clamp(0.7, 1.3)
+            ra = (stack * 16 + 128).round().clamp(0, 255).to(torch.uint8)
+            rb = (stack_b * 16 + 128).round().clamp(0, 255).to(torch.uint8)
+            rpipe = pipeline.RawMoviePipeline(gain, dev, 1.0, ref, 500.0, (300, 10), "catmull_rom", return_frames=True,
+                                              overlap=not args.no_overlap)
+            nraw = max(10, args.steps // 4)
+            for rr in rpipe.iterate([ra, rb][i % 2] for i in range(3)):
+                pass
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats()
+            m0 = torch.cuda.memory_allocated()
+            c0 = time.perf_counter()
+            for rr in rpipe.iterate([ra, rb][i % 2] for i in range(nraw)):
+                lastr = rr
+            torch.cuda.synchronize()
+            el_raw = time.perf_counter() - c0
+            peak_raw = torch.cuda.max_memory_allocated() - m0
+            shr = (lastr.field[:, :, 0, 0].transpose(0, 1) / 1.0).cpu()
+            del rr, lastr
+
+            def conditioned():
+                for i in range(nraw):
+                    yield mc.condition_movie([ra, rb][i % 2], gain)
+
+            for _ in pipe.iterate(mc.condition_movie(x, gain) for x in (ra, rb, ra)):
+                pass
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats()
+            c0 = time.perf_counter()
+            for rr in pipe.iterate(conditioned()):
+                pass
+            torch.cuda.synchronize()
+            el_cond = time.perf_counter() - c0
+            peak_cond = torch.cuda.max_memory_allocated() - m0
+            raw_u8 = {
+                "workload": f"the headline steps on {t}-frame {h}x{w} RAW uint8 movies + (h,w) gain reference: "
+                            "gain multiply and per-frame mean-zero fused into the kernels that read the raw bytes",
+                "frames_per_s": t * nraw / el_raw, "ms_per_step": 1e3 * el_raw / nraw, "steps": nraw,
+                "peak_extra_hbm_GB": peak_raw / 1e9,
+                "shifts_match_ground_truth": bool(torch.equal(shr, expect)),
+                "via_fp32_movie_ms_per_step": 1e3 * el_cond / nraw, "via_fp32_movie_peak_extra_hbm_GB": peak_cond / 1e9,
+                # compulsory bytes of the raw flow: the u8 frame read by the statistics, the estimator and the
+                # corrector, the corrected fp32 frame written once
+                "whole_step_frac_of_7_bytes_per_px": 7.0 * h * w * t / (el_raw / nraw) / 1e9 / HBM_PEAK_GBS,
+            }
+            del ra, rb, gain, rr
+        except Exception as e:
+            raw_u8 = {"error": repr(e)}
+
     # Secondary workload (reported, never the headline value): BASELINE.json configs[2], local
     # motion on a K3-sized stack -- 1024-px patches (6 x 10), B-spline warp, frame sum.
     secondary = None
@@ -406,6 +462,7 @@ def main():
             "cpu_baseline": cpu,
             "secondary": secondary,
             "fp16_storage": half_storage,
+            "raw_u8": raw_u8,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

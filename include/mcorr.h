@@ -324,6 +324,15 @@ int mc_warp_rigid_raw(const void* raw, int storage, const float* gain, const flo
                       const float* shifts_px, float* scratch, float* out_frames, float* out_sum, int phase,
                       void* stream);
 
+/* The tail of the rigid movie pipeline in two launches: integer-peak shifts (t,2) px of estimate_global_motion ->
+ * field (2,t) Angstrom (image_shifts_to_deformation_field, deformation_field_utils.py:129-162), the per-frame
+ * shifts the corrector uses (the field's spline at the frame times, correct_motion.py:57-72, lattice point
+ * (0,0), / pixel_spacing) and the weight tables of mc_warp_rigid_phase(phase 1) in `scratch`.  Results are
+ * bit for bit those of mc_spline_lattice + mc_warp_rigid_phase. */
+int mc_rigid_tables_from_shifts(const float* shifts, float pixel_spacing, const int* idx_t, const float* w_t,
+                                const float* w_y, const float* w_x, int nframes, int h, int w, float* field,
+                                float* shifts_px, float* scratch, void* stream);
+
 /* Rigid special case of mc_warp_frames: a (2,nt,1,1) field gives each frame ONE shift,
  * shifts_px[f] = (sy, sx) in pixels (device).  The coordinate chain is then separable
  * and the resample is a regular 5x5 separable correlation (see warp.hip).  Same

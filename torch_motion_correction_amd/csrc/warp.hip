@@ -423,6 +423,51 @@ __global__ void rigid_weights(const float* __restrict__ shifts, int nframes, int
   }
 }
 
+// pass 0 for the movie pipeline, everything between the peak search and the weight tables in ONE launch:
+// the pipeline's tail used to be six launches of a few microseconds each (shifts * pixel_spacing, a
+// contiguous copy, spline_lattice_kernel, another copy, / pixel_spacing, rigid_base), all on the
+// estimator's critical chain and each waiting for a wave slot under the previous movie's warp.  One
+// workgroup per (frame, axis): the frame's lattice value = the (2,t,1,1) field's spline in time at
+// t_f = f / (t - 1) -- spline_lattice_kernel's arithmetic in spline_lattice_kernel's order, lattice point
+// (0, 0), so the result is bit for bit what the generic route gives --, then rigid_base's reduction.
+//   field[axis][f] = shifts[f][axis] * ps;  shifts_px[f][axis] = lattice / ps;  S[f][axis] as rigid_base
+__global__ __launch_bounds__(256) void rigid_tail(const float* __restrict__ shifts, float ps, const int* __restrict__ idx_t,
+                                                  const float* __restrict__ w_t, const float* __restrict__ w_y,
+                                                  const float* __restrict__ w_x, int nframes, int h, int w,
+                                                  float* __restrict__ field, float* __restrict__ shifts_px,
+                                                  int* __restrict__ S) {
+  const int f = blockIdx.x, axis = blockIdx.y;
+  float vt = 0.f;
+  for (int kt = 0; kt < 4; ++kt) {
+    const float d = shifts[2 * idx_t[4 * f + kt] + axis] * ps;  // the field's node value (deformation_field_utils.py:129-162)
+    float vy = 0.f;
+    for (int ky = 0; ky < 4; ++ky) {
+      float vx = 0.f;
+      for (int kx = 0; kx < 4; ++kx) vx += d * w_x[kx];
+      vy += vx * w_y[ky];
+    }
+    vt += vy * w_t[4 * f + kt];
+  }
+  const float s = vt / ps;
+  if (threadIdx.x == 0) {
+    field[axis * nframes + f] = shifts[2 * f + axis] * ps;
+    shifts_px[2 * f + axis] = s;
+  }
+  const int n = axis == 0 ? h : w;
+  const float lim = 3.0f * (float)n + 16.f;
+  int di = 0x7fffffff;
+  for (int p = threadIdx.x; p < n; p += 256) {
+    const float u = grid_chain((float)p + s, (float)n);
+    const float d = floorf(u) - (float)p;
+    di = min(di, (int)fminf(fmaxf(d, -lim), lim));
+  }
+  for (int off = 32; off > 0; off >>= 1) di = min(di, __shfl_xor(di, off));
+  __shared__ int part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = di;
+  __syncthreads();
+  if (threadIdx.x == 0) S[2 * f + axis] = min(min(part[0], part[1]), min(part[2], part[3]));
+}
+
 struct RigidArgs {
   const float* frames;
   int nframes, h, w;
@@ -3188,6 +3233,8 @@ static int warp_rigid_impl(const void* frames_any, int storage, int nframes, int
     if (geom == 14) MC_RD_GO(F, S, NB, 1, 4);                  \
     else if (geom == 22) MC_RD_GO(F, S, NB, 2, 2);             \
     else if (geom == 24) MC_RD_GO(F, S, NB, 2, 4);             \
+    else if (geom == 23) MC_RD_GO(F, S, NB, 2, 3);             \
+    else if (geom == 43) MC_RD_GO(F, S, NB, 4, 3);             \
     else if (geom == 41) MC_RD_GO(F, S, NB, 4, 1);             \
     else if (geom == 42) MC_RD_GO(F, S, NB, 4, 2);             \
     else if (geom == 18) MC_RD_GO(F, S, NB, 1, 8);             \
@@ -3233,6 +3280,27 @@ static int warp_rigid_impl(const void* frames_any, int storage, int nframes, int
   if (out_frames && out_sum) hipLaunchKernelGGL((warp_rigid<true, true>), grid, block, 0, s, a);
   else if (out_frames) hipLaunchKernelGGL((warp_rigid<true, false>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((warp_rigid<false, true>), grid, block, 0, s, a);
+  return mc_check_launch();
+}
+
+// The movie pipeline's tail in two launches (rigid_tail + rigid_weights): integer-peak shifts (t,2) px ->
+// field (2,t) Angstrom, the warp's shifts_px (t,2) and its weight tables in `scratch` (the layout of
+// mc_warp_rigid_phase, phase 1).  idx_t / w_t: the 4 time taps per frame of the field's spline
+// (spline.axis_taps(t, linspace(0,1,t))), w_y / w_x: the taps of lattice point 0 on a 1-sample axis.
+int mc_rigid_tables_from_shifts(const float* shifts, float pixel_spacing, const int* idx_t, const float* w_t,
+                                const float* w_y, const float* w_x, int nframes, int h, int w, float* field,
+                                float* shifts_px, float* scratch, void* stream) {
+  if (!shifts || !idx_t || !w_t || !w_y || !w_x || !field || !shifts_px || !scratch) return MC_ERR_ARG;
+  if (nframes < 1 || h < 2 || w < 2 || !(pixel_spacing > 0.f) || (((uintptr_t)scratch) & 15)) return MC_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  float* Wy = scratch;
+  float* Wx = Wy + (int64_t)nframes * 5 * h;
+  int* S = reinterpret_cast<int*>(Wx + (int64_t)nframes * 5 * w);
+  const int n = h > w ? h : w;
+  hipLaunchKernelGGL(rigid_tail, dim3(nframes, 2), dim3(256), 0, s, shifts, pixel_spacing, idx_t, w_t, w_y, w_x, nframes,
+                     h, w, field, shifts_px, S);
+  hipLaunchKernelGGL(rigid_weights, dim3((n + 255) / 256, nframes, 2), dim3(256), 0, s, (const float*)shifts_px, nframes,
+                     h, w, (const int*)S, Wy, Wx);
   return mc_check_launch();
 }
 

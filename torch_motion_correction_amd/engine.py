@@ -230,7 +230,7 @@ def mask_spectrum(pl, dev):
     return pl.mhat
 
 
-def _global_spectra(img, pl):
+def _global_spectra(img, pl, split=False):
     """Filtered pruned spectra of all frames, (t, nkx, nky, 2), with normalize_image's
     statistics gathered inside K1 whenever the central box lies in the region K1 reads
     (always for near-square frames); otherwise a separate statistics pass."""
@@ -272,9 +272,15 @@ def _global_spectra(img, pl):
         if img.dtype == torch.float32:
             raise
         del T1, S
-        return _global_spectra(img.float(), pl)
+        return _global_spectra(img.float(), pl, split)
+    if AFTER_K1_HOOK is not None and not HOOK_AFTER_K2:
+        AFTER_K1_HOOK()
+    if split:  # the caller enqueues the column pass itself, possibly on another stream (global_stage_b)
+        return ("k2_pending", T1, S, fix, mhat)
     check(lib.mc_xc_cols_forward_fix(ptr(T1), ptr(pl.filt), ptr(S), ptr(pl.tw_col), t, g, ptr(fix),
                                      ptr(mhat), st), "mc_xc_cols_forward_fix")
+    if AFTER_K1_HOOK is not None and HOOK_AFTER_K2:
+        AFTER_K1_HOOK()
     return S
 
 
@@ -313,6 +319,34 @@ def global_shifts(img, reference_frame, pixel_spacing, b_factor, frequency_range
     dev = img.device
     pl = planmod.get_xc_plan(h, w, pixel_spacing, b_factor, frequency_range, dev)
     S = _global_spectra(img, pl)
+    return _shifts_from_spectra(S, t, reference_frame, pl)
+
+
+def global_stage_a(img, pixel_spacing, b_factor, frequency_range):
+    """First stage of global_shifts for the three-stage movie pipeline: the plan and K1 (the HBM-bound row
+    pass over the frames) on the current stream.  Returns an opaque state for ``global_stage_b``; its
+    tensors must be made known to the stream stage b runs on (``stage_tensors``)."""
+    t, h, w = img.shape
+    pl = planmod.get_xc_plan(h, w, pixel_spacing, b_factor, frequency_range, img.device)
+    return (t, pl, _global_spectra(img, pl, split=True))
+
+
+def stage_tensors(state):
+    r = state[2]
+    return [x for x in (r[1:] if isinstance(r, tuple) else (r,)) if isinstance(x, torch.Tensor)]
+
+
+def global_stage_b(state, reference_frame):
+    """Second stage: the column pass (when stage a left it pending), K3, K4 -> (t, 2) shifts, on the current stream."""
+    lib = _lib.load()
+    t, pl, r = state
+    if isinstance(r, tuple):
+        _, T1, S, fix, mhat = r
+        g = pl.geom
+        check(lib.mc_xc_cols_forward_fix(ptr(T1), ptr(pl.filt), ptr(S), ptr(pl.tw_col), t, g, ptr(fix),
+                                         ptr(mhat), stream_ptr(S.device)), "mc_xc_cols_forward_fix")
+    else:
+        S = r
     return _shifts_from_spectra(S, t, reference_frame, pl)
 
 
@@ -493,6 +527,8 @@ def frame_lattices(field, t, grid_type):
 
 
 RIGID_KERNEL_HOOK = None  # callable(fn) -> calls fn(); set by bench.py to time warp_rigid_dma alone
+HOOK_AFTER_K2 = False
+AFTER_K1_HOOK = None  # callable() invoked right after the global estimate's K1 has been enqueued (pipeline schedules)
 
 
 def rigid_tables(img, lattices, pixel_spacing):
@@ -512,6 +548,32 @@ def rigid_tables(img, lattices, pixel_spacing):
     check(lib.mc_warp_rigid_phase_t(ptr(img), STORE_F32, t, h, w, ptr(shifts_px), ptr(scratch), None, None, 1,
                                     stream_ptr(dev)), "mc_warp_rigid_phase")
     return shifts_px, scratch
+
+
+def rigid_tables_from_shifts(shifts, img_shape, pixel_spacing, grid_type):
+    """The movie pipeline's tail in two launches (mc_rigid_tables_from_shifts): (t,2) px shifts of the global
+    estimate -> ((2,t,1,1) Angstrom field, handle for ``warp(..., rigid=True, tables=handle)``); the same
+    numbers as image_shifts_to_deformation_field + frame_lattices + rigid_tables, bit for bit."""
+    lib = _lib.load()
+    t, h, w = img_shape
+    dev = shifts.device
+
+    def build():
+        lin = torch.linspace(0, 1, steps=t)
+        it, wt = spline.axis_taps(t, lin, grid_type)
+        _, w1 = spline.axis_taps(1, torch.linspace(0, 1, steps=10)[:1], grid_type)  # lattice point 0 of a 1-sample axis
+        return it.to(dev), wt.to(dev), w1[0].contiguous().to(dev)
+
+    idx_t, w_t, w1 = _cached(("rigid_tail_taps", str(dev), t, grid_type), build)
+    field = torch.empty((2, t), dtype=torch.float32, device=dev)
+    shifts_px = torch.empty((t, 2), dtype=torch.float32, device=dev)
+    nbytes = C.c_int64(0)
+    check(lib.mc_warp_rigid_scratch_bytes(t, h, w, C.byref(nbytes)), "mc_warp_rigid_scratch_bytes")
+    scratch = torch.empty((nbytes.value + 3) // 4, dtype=torch.float32, device=dev)
+    check(lib.mc_rigid_tables_from_shifts(ptr(shifts.contiguous()), float(pixel_spacing), ptr(idx_t), ptr(w_t), ptr(w1),
+                                          ptr(w1), t, h, w, ptr(field), ptr(shifts_px), ptr(scratch), stream_ptr(dev)),
+          "mc_rigid_tables_from_shifts")
+    return field[:, :, None, None], (shifts_px, scratch)
 
 
 def warp(img, lattices, pixel_spacing, want_frames=True, want_sum=False, rigid=False, tables=None):

@@ -51,21 +51,27 @@ class MoviePipeline:
         pe, pw = (int(x) for x in os.environ.get("MC_PIPE_PRIORITIES", "-1,0").split(","))
         self._s_est = torch.cuda.Stream(self.device, priority=pe) if overlap else None
         self._s_warp = torch.cuda.Stream(self.device, priority=pw) if overlap else None
+        self._s_rest = None  # third stream of the three-stage schedule, created on first use
+        self._tables = {}
 
     # the two stages, each enqueued on whatever stream is current
     def _estimate(self, img: torch.Tensor) -> torch.Tensor:
         t = img.shape[0]
         ref = t // 2 if self.reference_frame is None else int(self.reference_frame)
         shifts = engine.global_shifts(img, ref, self.pixel_spacing, self.b_factor, self.frequency_range)
-        return (shifts * self.pixel_spacing).transpose(0, 1)[:, :, None, None]  # dfu.py:129-162
+        return self._field_and_tables(img, shifts)
+
+    def _field_and_tables(self, img: torch.Tensor, shifts: torch.Tensor) -> torch.Tensor:
+        """(t,2) px shifts -> the (2,t,1,1) Angstrom field (dfu.py:129-162); everything of correct_motion that
+        only needs the field -- the per-frame lattice values and the rigid warp's weight tables -- is built
+        right here, on the ESTIMATOR's stream, in two launches (mc_rigid_tables_from_shifts; it used to be
+        seven, each waiting for a wave slot under the previous movie's warp), and handed to ``_prepare``."""
+        field, tables = engine.rigid_tables_from_shifts(shifts, tuple(img.shape), self.pixel_spacing, self.grid_type)
+        self._tables[id(img)] = tables
+        return field
 
     def _prepare(self, img: torch.Tensor, field: torch.Tensor):
-        """Everything of correct_motion that only needs the field: the per-frame lattices and the rigid
-        warp's weight tables (six launches of a few microseconds each).  Enqueued on the ESTIMATOR's
-        stream, behind its last kernel: they then run under the previous movie's warp instead of
-        holding up this movie's (the warp stream idled 56 us between two launches, 3 % of a step)."""
-        lat = engine.frame_lattices(field.contiguous(), img.shape[0], self.grid_type)
-        return engine.rigid_tables(img, lat, self.pixel_spacing)
+        return self._tables.pop(id(img))
 
     def _correct(self, img: torch.Tensor, tables):
         return engine.warp(img, None, self.pixel_spacing, want_frames=self.return_frames, want_sum=True,
@@ -98,30 +104,150 @@ class MoviePipeline:
             start.record(caller)
             self._s_est.wait_event(start)
             self._s_warp.wait_event(start)
+        import os
+
+        # MC_PIPE_SCHEDULE: k1first (default), abc (three stages, the warp alone), all (round 2: the whole
+        # estimator under the previous warp), k2first -- measured on 40 x 4096^2 (same box): 1.70 / 1.92 /
+        # 1.76-1.79 / 1.72-1.73 ms per step
+        if os.environ.get("MC_PIPE_SCHEDULE", "k1first") == "abc" and type(self) is MoviePipeline:
+            yield from self._iterate_three_stage(movies, call, caller)
+            return
+        sched = os.environ.get("MC_PIPE_SCHEDULE", "k1first")
+        k1_first = sched in ("k1first", "k2first")
+        engine.HOOK_AFTER_K2 = sched == "k2first"
         try:
+            pending = None  # k1first: (img, field, tables, ready) of the movie whose warp is not enqueued yet
             for img in movies:
                 with device_scope(dev):
                     img = self._check(img)
                     img.record_stream(self._s_est)
                     img.record_stream(self._s_warp)
+                    k1_done = torch.cuda.Event() if k1_first else None
                     with torch.cuda.stream(self._s_est):
-                        field = self._estimate(img)
+                        if k1_first:
+                            engine.AFTER_K1_HOOK = lambda: k1_done.record(self._s_est)
+                        try:
+                            field = self._estimate(img)
+                        finally:
+                            engine.AFTER_K1_HOOK = None
                         tables = self._prepare(img, field)
                         ready = torch.cuda.Event()
                         ready.record(self._s_est)
+
+                    def enqueue_warp(img_, field_, tables_, ready_, extra=None):
+                        with torch.cuda.stream(self._s_warp):
+                            self._s_warp.wait_event(ready_)
+                            if extra is not None:
+                                self._s_warp.wait_event(extra)  # the NEXT movie's K1 has left the HBM to this warp
+                            field_.record_stream(self._s_warp)
+                            for x in tables_:
+                                if isinstance(x, torch.Tensor):
+                                    x.record_stream(self._s_warp)
+                            return call(lambda: self._correct(img_, tables_))
+
+                    if not k1_first:
+                        frames, total = enqueue_warp(img, field, tables, ready)
+                        res = MovieResult(field, total, frames)
+                    else:
+                        res = None
+                        if pending is not None:
+                            pimg, pfield, ptables, pready = pending
+                            frames, total = enqueue_warp(pimg, pfield, ptables, pready, k1_done)
+                            res = MovieResult(pfield, total, frames)
+                        pending = (img, field, tables, ready)
+                if res is not None:
+                    yield res
+            if k1_first and pending is not None:
+                with device_scope(dev):
+                    pimg, pfield, ptables, pready = pending
                     with torch.cuda.stream(self._s_warp):
-                        self._s_warp.wait_event(ready)
-                        field.record_stream(self._s_warp)
-                        for x in tables:
+                        self._s_warp.wait_event(pready)
+                        pfield.record_stream(self._s_warp)
+                        for x in ptables:
                             if isinstance(x, torch.Tensor):
                                 x.record_stream(self._s_warp)
-                        frames, total = call(lambda: self._correct(img, tables))
-                yield MovieResult(field, total, frames)
+                        frames, total = call(lambda: self._correct(pimg, ptables))
+                yield MovieResult(pfield, total, frames)
         finally:
             with device_scope(dev):
                 for s in (self._s_est, self._s_warp):
                     done = torch.cuda.Event()
                     done.record(s)
+                    caller.wait_event(done)
+
+    def _iterate_three_stage(self, movies, call, caller):
+        """Three stages on three streams: A = K1 (the estimator's HBM-bound row pass), B = the rest of the
+        estimator and the warp's tables (latency-bound kernels with 32 KB of LDS per workgroup), C = the
+        warp.  Per period   [ A(m) || B(m-1) ]  then  [ C(m-1) ] :  the warp has the chip to itself (under
+        the two-stream overlap its launch stretched from 1.09 to 1.44-1.65 ms: K1 took its HBM share, K2-K4
+        only fit into a CU once a warp tile had retired), and B's workgroups fit beside K1's, which hold
+        64 KB of LDS per CU.  Events only; no host synchronisation."""
+        dev = self.device
+        if self._s_rest is None:
+            self._s_rest = torch.cuda.Stream(dev)
+        s_a, s_b, s_c = self._s_est, self._s_rest, self._s_warp
+        with device_scope(dev):
+            start = torch.cuda.Event()
+            start.record(caller)
+            s_b.wait_event(start)
+        t_ref = lambda img: (img.shape[0] // 2 if self.reference_frame is None else int(self.reference_frame))  # noqa: E731
+        pending = None   # (img, state, evA) of the movie whose stages B and C are not enqueued yet
+        ev_c = None      # end of the last enqueued warp
+
+        def stage_bc(p, ev_a_next):
+            nonlocal ev_c
+            pimg, pstate, pev_a = p
+            with torch.cuda.stream(s_b):
+                s_b.wait_event(pev_a)
+                if ev_c is not None:
+                    s_b.wait_event(ev_c)
+                for x in engine.stage_tensors(pstate):
+                    x.record_stream(s_b)
+                shifts = engine.global_stage_b(pstate, t_ref(pimg))
+                field = self._field_and_tables(pimg, shifts)
+                tables = self._prepare(pimg, field)
+                ev_b = torch.cuda.Event()
+                ev_b.record(s_b)
+            with torch.cuda.stream(s_c):
+                s_c.wait_event(ev_b)
+                if ev_a_next is not None:
+                    s_c.wait_event(ev_a_next)  # the next movie's K1 has left the HBM to this warp
+                field.record_stream(s_c)
+                for x in tables:
+                    if isinstance(x, torch.Tensor):
+                        x.record_stream(s_c)
+                frames, total = call(lambda: self._correct(pimg, tables))
+                ev_c = torch.cuda.Event()
+                ev_c.record(s_c)
+            return MovieResult(field, total, frames)
+
+        try:
+            for img in movies:
+                res = None
+                with device_scope(dev):
+                    img = self._check(img)
+                    for s_ in (s_a, s_b, s_c):
+                        img.record_stream(s_)
+                    with torch.cuda.stream(s_a):
+                        if ev_c is not None:
+                            s_a.wait_event(ev_c)
+                        state = engine.global_stage_a(img, self.pixel_spacing, self.b_factor, self.frequency_range)
+                        ev_a = torch.cuda.Event()
+                        ev_a.record(s_a)
+                    if pending is not None:
+                        res = stage_bc(pending, ev_a)
+                    pending = (img, state, ev_a)
+                if res is not None:
+                    yield res
+            if pending is not None:
+                with device_scope(dev):
+                    res = stage_bc(pending, None)
+                yield res
+        finally:
+            with device_scope(dev):
+                for s_ in (s_a, s_b, s_c):
+                    done = torch.cuda.Event()
+                    done.record(s_)
                     caller.wait_event(done)
 
     def run(self, movies: Iterable[torch.Tensor],
@@ -178,12 +304,11 @@ class RawMoviePipeline(MoviePipeline):
         rm = engine.RawMovie(img, self.gain, mean_zero=self.mean_zero)  # the statistics pass, on the estimator's stream
         self._rm[id(img)] = rm
         shifts = engine.global_shifts_raw(rm, ref, self.pixel_spacing, self.b_factor, self.frequency_range)
-        return (shifts * self.pixel_spacing).transpose(0, 1)[:, :, None, None]
+        return self._field_and_tables(img, shifts)
 
     def _prepare(self, img: torch.Tensor, field: torch.Tensor):
-        lat = engine.frame_lattices(field.contiguous(), img.shape[0], self.grid_type)
         rm = self._rm.pop(id(img))
-        shifts_px, scratch = engine.rigid_tables(img, lat, self.pixel_spacing)
+        shifts_px, scratch = self._tables.pop(id(img))
         return shifts_px, scratch, rm.mu, rm
 
     def _correct(self, img: torch.Tensor, tables):
