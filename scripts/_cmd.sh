@@ -1,5 +1,9 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 600 python -m pytest tests -x -q -m gpu -k "pipeline or movies or sharded or raw or fused" 2>&1 | tail -3
-for sch in k1first k1first; do
-MC_PIPE_SCHEDULE=$sch timeout -k 10 300 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-secondary 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['value'], d['ms_per_step'], 'warp', r['ms_per_launch'], 'frac', r['frac'], 'solo', r['ms_per_launch_unshared'], 'whole', r['whole_step_frac'], d['config']['shifts_match_ground_truth'])"
-done
+timeout -k 10 900 python bench.py --steps 40 > gpurun_out/e23_bench.json 2> gpurun_out/e23_bench.err; echo rc=$?
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/e23_bench.json').read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'], d['roofline']['whole_step_frac'], d['roofline']['frac'], d['cpu_baseline'])
+print({k: d['raw_u8'][k] for k in ('ms_per_step','via_fp32_movie_ms_per_step','shifts_match_ground_truth')})
+print({k: d['fp16_storage'][k] for k in ('ms_per_step','shifts_match_ground_truth')})
+PY

@@ -753,9 +753,17 @@ __device__ __forceinline__ void rigid_strip_dma(const RigidArgs& a, const float4
 // tile of 256 WX x 8 WY output pixels per workgroup of 64 WX WY threads.  (1, 4) is the 256 x 32
 // tile of round 1; wider tiles make every row piece a workgroup touches longer (1 KiB per 256
 // columns: fewer partial 128-byte lines at the two ends, longer runs inside a DRAM page).
+#ifndef RIGID_DMA_MINW
+#define RIGID_DMA_MINW 4
+#endif
+#if !defined(RIGID_DMA_VGPRS) || defined(MC_EXPERIMENTS)
+#define RIGID_DMA_VGPR_ATTR
+#else
+#define RIGID_DMA_VGPR_ATTR __attribute__((amdgpu_num_vgpr(RIGID_DMA_VGPRS)))
+#endif
 template <bool WRITE_FRAMES, bool WRITE_SUM, int NBUF, int WX, int WY>
-__global__ __launch_bounds__(RIGID_LANES* WX* WY, NBUF == 1 ? 4 : 2)  // 16 (8) waves per CU whatever the tile
-void warp_rigid_dma(RigidArgs a) {
+__global__ __launch_bounds__(RIGID_LANES* WX* WY, NBUF == 1 ? RIGID_DMA_MINW : 2)  // 16 (8) waves per CU whatever the tile
+RIGID_DMA_VGPR_ATTR void warp_rigid_dma(RigidArgs a) {
   constexpr int NWAVES = WX * WY;
   constexpr int TROWS = WY * RIGID_ROWS + 4;       // input rows per tile
   constexpr int QUADS = WX * RIGID_LANES + 4;      // float4 columns per tile row

@@ -1039,6 +1039,8 @@ def global_shifts_raw(rm: RawMovie, reference_frame, pixel_spacing, b_factor, fr
                                      ptr(rm.mean_rstd), ptr(T1), ptr(pl.tw_row), t, g,
                                      ptr(pl.chord) if (pl.chord is not None and USE_ROW_CHORDS) else None, st),
           "mc_xc_rows_forward_raw")
+    if AFTER_K1_HOOK is not None:
+        AFTER_K1_HOOK()
     check(lib.mc_xc_cols_forward(ptr(T1), ptr(pl.filt), ptr(S), ptr(pl.tw_col), t, g, st), "mc_xc_cols_forward")
     del T1
     return _shifts_from_spectra(S, t, reference_frame, pl)
