@@ -186,8 +186,10 @@ int mc_xc_rows_forward_stats_t(const void* src, int storage, const int64_t* job_
 /* N2: K1 from the raw bytes of a u8 / i16 movie, conditioned on the fly (no fp32 movie):
  *   rows of (raw * gain - job_sub[job]) * mean_rstd[1] * mask  ->  T1, as mc_xc_rows_forward writes it.
  * `gain` has the frames' row pitch (whole-frame jobs); job_sub / mean_rstd come from mc_raw_movie_stats;
- * follow with mc_xc_cols_forward (no fix-up: the statistics are known before this pass).  4096-column
- * frames, 16-byte aligned buffers, row_stride % 8 == 0; anything else: MC_ERR_UNSUPPORTED. */
+ * follow with mc_xc_cols_forward / mc_xcg_cols_forward (no fix-up: the statistics are known before this pass).
+ * mc_xc_rows_forward_raw: power-of-two widths (4096 columns with 16-byte aligned buffers and row_stride % 8 == 0 on
+ * the wave-per-row engine, the others on the workgroup engine); mc_xcg_rows_forward_raw: rows of 5760 / 11520
+ * samples (the K3 formats; `line` = the direct 2880 / 5760-point plan).  Anything else: MC_ERR_UNSUPPORTED. */
 int mc_xc_rows_forward_raw(const void* raw, int storage, const float* gain, const int64_t* job_off,
                            int64_t row_stride, const float* mask, const float* job_sub, const float* mean_rstd,
                            void* T1, const void* tw_row, int njobs, const mc_xc_geom* q, const int* row_chord,
@@ -433,6 +435,11 @@ int mc_xcg_rows_forward(const float* src, const int64_t* job_off, int64_t row_st
                         const int* job_expo, const float* mask, const float* mean_rstd, void* T1,
                         const void* tw_row, const mc_xc_line* line, int njobs,
                         const mc_xc_geom* geom, void* stream);
+/* N2: the K3-format rows (5760 / 11520 samples) from raw u8 / i16 bytes; see mc_xc_rows_forward_raw. */
+int mc_xcg_rows_forward_raw(const void* raw, int storage, const float* gain, const int64_t* job_off,
+                            int64_t row_stride, const float* mask, const float* job_sub, const float* mean_rstd,
+                            void* T1, const void* tw_row, const mc_xc_line* line, int njobs, const mc_xc_geom* q,
+                            void* stream);
 int mc_xcg_cols_forward(const void* T1, const float* filt, void* S, const mc_xc_line* line,
                         int njobs, const mc_xc_geom* geom, void* stream);
 int mc_xcg_cols_inverse(const void* S_cur, const int* cur_idx, const void* S_ref,

@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-bash scripts/gpu_round_profiles.sh > gpurun_out/round_profiles.log 2>&1; echo "round rc=$?"
-tail -20 gpurun_out/round_profiles.log
+timeout -k 10 900 python -m pytest tests -x -q -m gpu -k "raw or fused or pipeline" 2>&1 | tail -8

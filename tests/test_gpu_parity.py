@@ -1884,6 +1884,31 @@ def test_fused_raw_path_equals_conditioning_then_the_fp32_path_and_the_oracle(mc
     assert float(err) <= REL
 
 
+@pytest.mark.parametrize("shape,dtype", [((5, 512, 1024), torch.uint8), ((5, 1024, 512), torch.int16),
+                                         ((3, 4092, 5760), torch.uint8), ((3, 4092, 5760), torch.int16)])
+def test_fused_raw_path_on_other_engines(mc, dev, shape, dtype):
+    """The raw K1 also exists on the workgroup-per-row engine (power-of-two widths other than 4096) and on the
+    mixed-radix rows of the K3 formats (mc_xcg_rows_forward_raw, 5760 columns); the raw warp takes any row of
+    whole quads.  Same checks against condition_movie + the fp32 path; the fused route must really have been
+    taken (no fp32 movie: the engine function raises instead of falling back)."""
+    from torch_motion_correction_amd import engine
+
+    t, h, w = shape
+    raw, gain, dy, dx = _raw_drift_movie(t, h, w, dtype, 31, 4)
+    rd, gd = raw.to(dev), gain.to(dev)
+    rm = engine.RawMovie(rd, gd)
+    sh = engine.global_shifts_raw(rm, t // 2, 1.0, 500.0, (300, 10))  # McorrUnsupported if no fused kernel
+    field, total, frames = mc.motion_correct_raw(rd, gd, 1.0, return_frames=True)
+    assert torch.equal(field[:, :, 0, 0].T, sh)
+    img = mc.condition_movie(rd, gd)
+    fa = mc.estimate_global_motion(img, 1.0)
+    sa, fra = mc.motion_correct_sum(img, fa, 1.0, return_frames=True)
+    assert torch.equal(field, fa)
+    assert rel_err(frames, fra) <= 1e-5 and rel_err(total, sa) <= 1e-5
+    expect = torch.tensor([[dy[f] - dy[t // 2], dx[f] - dx[t // 2]] for f in range(t)], dtype=torch.float32)
+    assert torch.equal(field[:, :, 0, 0].T.cpu(), expect)
+
+
 def test_raw_movie_statistics_match_a_float64_reference(mc, dev):
     from torch_motion_correction_amd import engine
 

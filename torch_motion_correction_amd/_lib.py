@@ -93,6 +93,7 @@ SIGNATURES = {
     "mc_condition_movie": [vp, i32, vp, i32, i64, i32, vp, vp, vp],
     "mc_raw_movie_stats": [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp],
     "mc_xc_rows_forward_raw": [vp, i32, vp, vp, i64, vp, vp, vp, vp, vp, i32, GP, vp, vp],
+    "mc_xcg_rows_forward_raw": [vp, i32, vp, vp, i64, vp, vp, vp, vp, vp, LP, i32, GP, vp],
     "mc_rigid_tables_from_shifts": [vp, f32, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp],
     "mc_warp_rigid_raw": [vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp],
     "mc_condition_movie_hot": [vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp],

@@ -366,8 +366,9 @@ def motion_correct_raw(movie, gain, pixel_spacing, reference_frame=None, b_facto
     fused into the kernels that read the raw bytes: one statistics pass, then the estimator's row transform and
     the rigid warp compute ``raw * gain - frame mean`` on the fly.  No conditioned fp32 movie is allocated.
     Returns ``(field (2,t,1,1) Angstrom, sum (h,w)[, frames (t,h,w)])`` -- what ``condition_movie`` followed by
-    ``estimate_global_motion`` and ``motion_correct_sum`` return.  Frame shapes without a fused kernel
-    (anything but 4096-column frames at the moment) take exactly that route, on an fp32 copy."""
+    ``estimate_global_motion`` and ``motion_correct_sum`` return.  Fused kernels exist for power-of-two frame
+    widths and the K3 formats (5760 / 11520 columns), rows of whole quads, at most 256 frames; any other shape
+    takes exactly that route, on an fp32 copy."""
     out_dev = _out_device(movie, device)
     dev = require_gpu(out_dev)
     raw = movie.detach().to(dev)

@@ -33,12 +33,15 @@
 // flight per workgroup (N = 2048: the whole workgroup on one row; N = 512: one wavefront
 // per row, four rows at a time).  Each sub-group owns a pair of LDS lines (ping-pong: one
 // barrier per pass); twiddles live in registers for the whole row loop.
-template <int LOGN, bool STATS>
+// RAW (N2): 1 = u8, 2 = i16 samples conditioned on the fly as raw * gain - job_sub[job] (whole-frame jobs:
+// `gain` has the frames' row pitch); no statistics then.
+template <int LOGN, bool STATS, int RAW = 0>
 __global__ __launch_bounds__(MC_WG) void xc_rows_fwd(
-    const float* __restrict__ src, const int64_t* __restrict__ job_off, int64_t row_stride,
+    const void* __restrict__ src_any, const int64_t* __restrict__ job_off, int64_t row_stride,
     const int* __restrict__ job_expo, const float* __restrict__ mask,
     const float* __restrict__ mean_rstd, cfloat* __restrict__ T1,
-    const cfloat* __restrict__ tw_row, XcGeom g, XcBox box, double* __restrict__ stats_acc) {
+    const cfloat* __restrict__ tw_row, XcGeom g, XcBox box, double* __restrict__ stats_acc,
+    const float* __restrict__ gain, const float* __restrict__ job_sub) {
   constexpr int N = 1 << LOGN;  // complex length = W/2
   constexpr int NT = fft_threads(N), SG = MC_WG / NT;
   constexpr int R0 = FftPlan<N>::radix(0), NB0 = N / R0, IT0 = (NB0 + NT - 1) / NT;
@@ -53,10 +56,11 @@ __global__ __launch_bounds__(MC_WG) void xc_rows_fwd(
   const int job = blockIdx.x;
   const int grp = blockIdx.y;
   const int RG = g.RG;
-  const float mean = mean_rstd ? mean_rstd[0] : 0.f;
+  const float mean = RAW ? job_sub[job] : (mean_rstd ? mean_rstd[0] : 0.f);
   const float rstd = mean_rstd ? mean_rstd[1] : 1.f;
   const int expo = job_expo ? job_expo[job] : (mask ? 1 : 0);
-  const float* base = src + job_off[job];
+  constexpr int SB = RAW == 1 ? 1 : RAW == 2 ? 2 : 4;
+  const char* base = static_cast<const char*>(src_any) + job_off[job] * SB;
   FftTwiddles<N> T;
   T.template init<-1>(lt, tw_row, 2);
 
@@ -64,7 +68,13 @@ __global__ __launch_bounds__(MC_WG) void xc_rows_fwd(
   float st_s = 0.f, st_q = 0.f;  // sum and sum of squares of (x - mean_rstd[0]) inside the box
   for (int r = sg; r < RG; r += SG) {  // RG % SG == 0: every sub-group runs the same trip count
     const int y = g.y0 + grp * RG + r;
-    const float* row = base + (int64_t)y * row_stride;
+    const char* rowb = base + (int64_t)y * row_stride * SB;
+    const float* grow = RAW ? gain + (int64_t)y * row_stride : nullptr;
+    auto row_at = [&](int xx) -> float {
+      if constexpr (RAW == 1) return (float)reinterpret_cast<const unsigned char*>(rowb)[xx] * grow[xx];
+      else if constexpr (RAW == 2) return (float)reinterpret_cast<const short*>(rowb)[xx] * grow[xx];
+      else return reinterpret_cast<const float*>(rowb)[xx];
+    };
     const float* mrow = mask + (int64_t)y * g.W;
     cfloat px[IT0][R0], mk[IT0][R0];
 #pragma unroll
@@ -74,7 +84,7 @@ __global__ __launch_bounds__(MC_WG) void xc_rows_fwd(
       for (int q = 0; q < R0; ++q) {
         const int x = 2 * (j + q * NB0);
         const bool on = (NB0 % NT == 0 || j < NB0) && x >= g.x0 && x < g.x1;
-        px[it][q] = on ? cmake(row[x], row[x + 1]) : cmake(mean, mean);
+        px[it][q] = on ? cmake(row_at(x), row_at(x + 1)) : cmake(mean, mean);
         mk[it][q] = (on && expo > 0) ? cmake(mrow[x], mrow[x + 1]) : cmake(on ? 1.f : 0.f, on ? 1.f : 0.f);
       }
     }
@@ -1678,8 +1688,9 @@ static int rows_forward_impl(const float* src, const int64_t* job_off, int64_t r
     auto k = stats_acc ? xc_rows_fwd<L, true> : xc_rows_fwd<L, false>;
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, grid, dim3(MC_WG), lds, (hipStream_t)stream, src, job_off, row_stride,
-                       job_expo, mask, mean_rstd, (cfloat*)T1, (const cfloat*)tw_row, g, b, stats_acc);
+    hipLaunchKernelGGL(k, grid, dim3(MC_WG), lds, (hipStream_t)stream, (const void*)src, job_off, row_stride,
+                       job_expo, mask, mean_rstd, (cfloat*)T1, (const cfloat*)tw_row, g, b, stats_acc,
+                       (const float*)nullptr, (const float*)nullptr);
   });
   return mc_check_launch();
 }
@@ -1776,8 +1787,9 @@ int mc_xc_rows_forward_stats_t(const void* src_any, int storage, const int64_t* 
 }
 
 // N2: K1 straight from the raw bytes of a u8 / i16 movie: A = (raw * gain - sub[job]) * mean_rstd[1] * mask.
-// Whole-frame jobs of 4096-column frames (the wave-per-row engine); anything else is MC_ERR_UNSUPPORTED and
-// the caller conditions the movie into an fp32 copy first (mc_condition_movie).
+// Whole-frame jobs: 4096-column frames on the wave-per-row engine, any other power-of-two width on the
+// workgroup engine (mc_xcg_rows_forward_raw has the K3 formats); anything else is MC_ERR_UNSUPPORTED and the
+// caller conditions the movie into an fp32 copy first (mc_condition_movie).
 int mc_xc_rows_forward_raw(const void* raw, int storage, const float* gain, const int64_t* job_off,
                            int64_t row_stride, const float* mask, const float* job_sub, const float* mean_rstd,
                            void* T1, const void* tw_row, int njobs, const mc_xc_geom* q, const int* row_chord,
@@ -1789,8 +1801,28 @@ int mc_xc_rows_forward_raw(const void* raw, int storage, const float* gain, cons
   if (!raw || !gain || !job_off || !mask || !job_sub || !mean_rstd || !T1 || !tw_row || njobs < 1) return MC_ERR_ARG;
   const uintptr_t al = reinterpret_cast<uintptr_t>(raw) | reinterpret_cast<uintptr_t>(gain) |
                        reinterpret_cast<uintptr_t>(mask);
-  if (!(g.W == 2 * WF_N && g.nkx <= 512 && (g.ny % 8) == 0 && (al & 15) == 0 && (row_stride & 7) == 0))
-    return MC_ERR_UNSUPPORTED;
+  if (!(g.W == 2 * WF_N && g.nkx <= 512 && (g.ny % 8) == 0 && (al & 15) == 0 && (row_stride & 7) == 0)) {
+    // any other power-of-two width: the workgroup-per-row engine, element-wise loads of raw and gain
+    const size_t lds = rows_lds_bytes(g.W / 2, g);
+    if (lds > 160 * 1024) return MC_ERR_ARG;
+    const int logn = mc_ilog2(g.W) - 1;
+    dim3 gridw(njobs, g.ny / g.RG);
+    XcBox bb{0, 0, 0, 0};
+    MC_DISPATCH_LOG(logn, {
+      if (storage == MC_STORE_U8) {
+        auto k = xc_rows_fwd<L, false, 1>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, gridw, dim3(MC_WG), lds, (hipStream_t)stream, raw, job_off, row_stride, (const int*)nullptr,
+                           mask, mean_rstd, (cfloat*)T1, (const cfloat*)tw_row, g, bb, (double*)nullptr, gain, job_sub);
+      } else {
+        auto k = xc_rows_fwd<L, false, 2>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, gridw, dim3(MC_WG), lds, (hipStream_t)stream, raw, job_off, row_stride, (const int*)nullptr,
+                           mask, mean_rstd, (cfloat*)T1, (const cfloat*)tw_row, g, bb, (double*)nullptr, gain, job_sub);
+      }
+    });
+    return mc_check_launch();
+  }
   const int ngroups = (g.ny + WF_ROWS_PER_WG - 1) / WF_ROWS_PER_WG;
   dim3 grid((ngroups + 7) / 8 * 8, njobs);
   XcBox b{0, 0, 0, 0};

@@ -118,12 +118,15 @@ __device__ __forceinline__ void xcg_line_fft(cfloat* line, int tid, const XcLine
 }
 
 
-template <int LOGM>
+// RAW (N2): 1 = u8, 2 = i16 samples conditioned on the fly as raw * gain - job_sub[job] (`gain` has the
+// frames' row pitch: whole-frame jobs; mc_raw_movie_stats supplies job_sub and mean_rstd[1])
+template <int LOGM, int RAW = 0>
 __global__ __launch_bounds__(MC_WG) void xcg_rows_fwd(
-    const float* __restrict__ src, const int64_t* __restrict__ job_off, int64_t row_stride,
+    const void* __restrict__ src_any, const int64_t* __restrict__ job_off, int64_t row_stride,
     const int* __restrict__ job_expo, const float* __restrict__ mask,
     const float* __restrict__ mean_rstd, cfloat* __restrict__ T1,
-    const cfloat* __restrict__ tw_row, XcLine ln, XcGeom g) {
+    const cfloat* __restrict__ tw_row, XcLine ln, XcGeom g, const float* __restrict__ gain,
+    const float* __restrict__ job_sub) {
   constexpr int M = mc_line_m(LOGM);
   // direct (mixed-radix) lines: the transform's outputs go back into the line itself and the unpack
   // reads Z[k], Z[n-k] from it -- no zlo / zhi copies: 48 instead of 57 KB of LDS for 5760-column
@@ -137,13 +140,21 @@ __global__ __launch_bounds__(MC_WG) void xcg_rows_fwd(
   const int tid = threadIdx.x;
   const int job = blockIdx.x, grp = blockIdx.y;
   const int RG = g.RG, n = ln.n;
-  const float mean = mean_rstd ? mean_rstd[0] : 0.f;
+  const float mean = RAW ? job_sub[job] : (mean_rstd ? mean_rstd[0] : 0.f);
   const float rstd = mean_rstd ? mean_rstd[1] : 1.f;
   const int expo = job_expo ? job_expo[job] : (mask ? 1 : 0);
-  const float* base = src + job_off[job];
+  constexpr int SB = RAW == 1 ? 1 : RAW == 2 ? 2 : 4;
+  const char* base = static_cast<const char*>(src_any) + job_off[job] * SB;
   for (int r = 0; r < RG; ++r) {
     const int y = g.y0 + grp * RG + r;
-    const float* row = base + (int64_t)y * row_stride;
+    const char* rowb = base + (int64_t)y * row_stride * SB;
+    const float* grow = RAW ? gain + (int64_t)y * row_stride : nullptr;
+    // one sample as the estimator sees it: the fp32 frame, or raw * gain (the mean comes off below)
+    auto row_at = [&](int x) -> float {
+      if constexpr (RAW == 1) return (float)reinterpret_cast<const unsigned char*>(rowb)[x] * grow[x];
+      else if constexpr (RAW == 2) return (float)reinterpret_cast<const short*>(rowb)[x] * grow[x];
+      else return reinterpret_cast<const float*>(rowb)[x];
+    };
     const float* mrow = mask + (int64_t)y * g.W;
     if (g.W & 1) {
       // odd width: no two-samples-per-point packing; the row is a length-W complex line with zero
@@ -151,7 +162,7 @@ __global__ __launch_bounds__(MC_WG) void xcg_rows_fwd(
       auto load1 = [&](int x) {
         cfloat v = cmake(0.f, 0.f);
         if (x >= g.x0 && x < g.x1) {
-          v.x = (row[x] - mean) * rstd;
+          v.x = (row_at(x) - mean) * rstd;
           if (expo > 0) {
             const float m0 = mrow[x];
             for (int e = 0; e < expo; ++e) v.x *= m0;
@@ -170,7 +181,7 @@ __global__ __launch_bounds__(MC_WG) void xcg_rows_fwd(
       const int x = 2 * j;
       cfloat v = cmake(0.f, 0.f);
       if (x >= g.x0 && x < g.x1) {
-        v = cmake((row[x] - mean) * rstd, (row[x + 1] - mean) * rstd);
+        v = cmake((row_at(x) - mean) * rstd, (row_at(x + 1) - mean) * rstd);
         if (expo > 0) {
           const float m0 = mrow[x], m1 = mrow[x + 1];
           for (int e = 0; e < expo; ++e) {
@@ -497,9 +508,40 @@ int mc_xcg_rows_forward(const float* src, const int64_t* job_off, int64_t row_st
   MC_DISPATCH_LOGM(logm, {
     auto k = xcg_rows_fwd<L>;
     MC_SET_LDS(k, lds);
-    hipLaunchKernelGGL(k, grid, dim3(MC_WG), lds, (hipStream_t)stream, src, job_off, row_stride,
-                       job_expo, mask, mean_rstd, (cfloat*)T1, (const cfloat*)tw_row, ln, g);
+    hipLaunchKernelGGL(k, grid, dim3(MC_WG), lds, (hipStream_t)stream, (const void*)src, job_off, row_stride,
+                       job_expo, mask, mean_rstd, (cfloat*)T1, (const cfloat*)tw_row, ln, g, (const float*)nullptr,
+                       (const float*)nullptr);
   });
+  return mc_check_launch();
+}
+
+// N2: the same row pass from the raw bytes of a u8 / i16 movie (whole-frame jobs), for the K3 formats: rows of
+// 5760 / 11520 samples (direct mixed-radix lines of 2880 / 5760 points).  Other lengths: MC_ERR_UNSUPPORTED.
+int mc_xcg_rows_forward_raw(const void* raw, int storage, const float* gain, const int64_t* job_off,
+                            int64_t row_stride, const float* mask, const float* job_sub, const float* mean_rstd,
+                            void* T1, const void* tw_row, const mc_xc_line* line, int njobs, const mc_xc_geom* q,
+                            void* stream) {
+  if (storage != MC_STORE_U8 && storage != MC_STORE_I16) return MC_ERR_UNSUPPORTED;
+  XcGeom g; XcLine ln; int logm;
+  int rc = geom_from_g(q, &g);
+  if (rc) return rc;
+  if (g.W & 1) return MC_ERR_UNSUPPORTED;
+  if ((rc = line_from(line, g.W / 2, &ln, &logm, true, g.nkx + 1))) return rc;
+  if (!raw || !gain || !job_off || !mask || !job_sub || !mean_rstd || !T1 || !tw_row || njobs < 1) return MC_ERR_ARG;
+  if (logm != 22 && logm != 23) return MC_ERR_UNSUPPORTED;
+  const size_t lds = sizeof(cfloat) * ((size_t)lds_len(line->M) + (size_t)g.nkx * (g.RG + 1));
+  if (lds > 160 * 1024) return MC_ERR_ARG;
+  dim3 grid(njobs, g.ny / g.RG);
+#define MC_XCG_RAW(L, R)                                                                                         \
+  do {                                                                                                           \
+    auto k = xcg_rows_fwd<L, R>;                                                                                 \
+    MC_SET_LDS(k, lds);                                                                                          \
+    hipLaunchKernelGGL(k, grid, dim3(MC_WG), lds, (hipStream_t)stream, raw, job_off, row_stride, (const int*)nullptr, \
+                       mask, mean_rstd, (cfloat*)T1, (const cfloat*)tw_row, ln, g, gain, job_sub);               \
+  } while (0)
+  if (logm == 22) { if (storage == MC_STORE_U8) MC_XCG_RAW(22, 1); else MC_XCG_RAW(22, 2); }
+  else { if (storage == MC_STORE_U8) MC_XCG_RAW(23, 1); else MC_XCG_RAW(23, 2); }
+#undef MC_XCG_RAW
   return mc_check_launch();
 }
 #endif

@@ -1010,18 +1010,21 @@ class RawMovie:
 
 
 def raw_fused_supported(raw, pl):
-    """Shapes the fused raw kernels take (the C side is the authority: anything else answers
-    MC_ERR_UNSUPPORTED and the caller conditions the movie into an fp32 copy)."""
+    """Shapes the fused raw kernels take (a shortcut: the C side is the authority and answers
+    MC_ERR_UNSUPPORTED for anything else; the caller then conditions the movie into an fp32 copy).  K1 from
+    raw bytes exists for power-of-two widths (4096: the wave-per-row engine) and the K3 formats' rows of 5760 /
+    11520 samples; the raw warp needs rows of whole quads and at most 256 frames."""
     t, h, w = raw.shape
     g = pl.geom
-    return (raw.dtype in (torch.uint8, torch.int16) and w == 4096 and planmod.native_rows(g)
-            and planmod.native_height(g.H) and g.nkx <= 512 and g.ny % 8 == 0 and raw.data_ptr() % 16 == 0)
+    rows_ok = planmod.native_rows(g) or (w % 2 == 0 and planmod.row_line_length(w) in (2880, 5760)
+                                        and planmod.USE_DIRECT_LINES)
+    return raw.dtype in (torch.uint8, torch.int16) and rows_ok and w % 4 == 0 and t <= 256 and raw.data_ptr() % 16 == 0
 
 
 def global_shifts_raw(rm: RawMovie, reference_frame, pixel_spacing, b_factor, frequency_range):
-    """global_shifts for a RawMovie: K1 reads the raw bytes (mc_xc_rows_forward_raw), the statistics are
-    known beforehand, so the column pass needs no fix-up.  Raises McorrUnsupported for shapes without a
-    fused kernel."""
+    """global_shifts for a RawMovie: K1 reads the raw bytes (mc_xc_rows_forward_raw / mc_xcg_rows_forward_raw), the
+    statistics are known beforehand, so the plain column pass follows.  Raises McorrUnsupported for shapes
+    without a fused kernel."""
     lib = _lib.load()
     t, h, w = rm.shape
     dev = rm.raw.device
@@ -1033,15 +1036,27 @@ def global_shifts_raw(rm: RawMovie, reference_frame, pixel_spacing, b_factor, fr
     st = stream_ptr(dev)
     job_off = _cached(("frame_off", str(dev), t, h, w),
                       lambda: torch.arange(t, device=dev, dtype=torch.int64) * (h * w))
-    T1 = torch.empty((t, g.nkx, g.ny, 2), dtype=torch.float32, device=dev)
     S = torch.empty((t, g.nkx, g.nky, 2), dtype=torch.float32, device=dev)
-    check(lib.mc_xc_rows_forward_raw(ptr(rm.raw), rm.kind, ptr(rm.gain), ptr(job_off), w, ptr(pl.mask), ptr(rm.sub),
-                                     ptr(rm.mean_rstd), ptr(T1), ptr(pl.tw_row), t, g,
-                                     ptr(pl.chord) if (pl.chord is not None and USE_ROW_CHORDS) else None, st),
-          "mc_xc_rows_forward_raw")
-    if AFTER_K1_HOOK is not None:
-        AFTER_K1_HOOK()
-    check(lib.mc_xc_cols_forward(ptr(T1), ptr(pl.filt), ptr(S), ptr(pl.tw_col), t, g, st), "mc_xc_cols_forward")
+    # row pass in chunks of frames when the transposed intermediate would be large (K3 formats: 0.4 GB per 10 frames)
+    per_job = g.nkx * g.ny * 8
+    chunk = max(1, min(t, WORKSPACE_BYTES // per_job))
+    T1 = torch.empty((chunk, g.nkx, g.ny, 2), dtype=torch.float32, device=dev)
+    chord = ptr(pl.chord) if (pl.chord is not None and USE_ROW_CHORDS) else None
+    for a in range(0, t, chunk):
+        n = min(chunk, t - a)
+        off, sub = job_off[a:a + n], rm.sub[a:a + n]
+        if planmod.native_rows(g):
+            check(lib.mc_xc_rows_forward_raw(ptr(rm.raw), rm.kind, ptr(rm.gain), ptr(off), w, ptr(pl.mask), ptr(sub),
+                                             ptr(rm.mean_rstd), ptr(T1), ptr(pl.tw_row), n, g, chord, st),
+                  "mc_xc_rows_forward_raw")
+        else:
+            line, _ = planmod.line_plan(planmod.row_line_length(g.W), -1, dev, keep=planmod.row_line_keep(g.W, g.nkx))
+            check(lib.mc_xcg_rows_forward_raw(ptr(rm.raw), rm.kind, ptr(rm.gain), ptr(off), w, ptr(pl.mask), ptr(sub),
+                                              ptr(rm.mean_rstd), ptr(T1), ptr(pl.tw_row), line, n, g, st),
+                  "mc_xcg_rows_forward_raw")
+        if a + n >= t and AFTER_K1_HOOK is not None:
+            AFTER_K1_HOOK()
+        check(_k2(lib, g, dev, T1, pl.filt, S[a:a + n], pl.tw_col, n, st), "xc cols forward")
     del T1
     return _shifts_from_spectra(S, t, reference_frame, pl)
 
