@@ -1496,13 +1496,33 @@ __device__ __forceinline__ void rigid_raw_read4(unsigned rawrow, unsigned (&d)[4
   }
 }
 
+// The strip on 2-float vectors: at two waves per SIMD (all the 93 KB gain cache allows) the kernel is bound by
+// vector-instruction ISSUE, one instruction per ~5 cycles and wave, and v_pk_fma_f32 does two of the separable
+// passes' multiply-adds per issue slot (mc_wave_fft.h's K1 is written the same way for the same reason).  Lane
+// arithmetic and its order are rigid_dot5's, so the results are those of the scalar strip bit for bit.
+typedef float rr_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ rr_f2 rr_dot5(const rr_f2 (&wv)[5], rr_f2 e0, rr_f2 e1, rr_f2 e2, rr_f2 e3, rr_f2 e4) {
+  rr_f2 r = wv[0] * e0;
+  r = __builtin_elementwise_fma(wv[1], e1, r);
+  r = __builtin_elementwise_fma(wv[2], e2, r);
+  r = __builtin_elementwise_fma(wv[3], e3, r);
+  return __builtin_elementwise_fma(wv[4], e4, r);
+}
+
 template <bool WRITE_FRAMES, bool WRITE_SUM, bool FULL, int KIND>
 __device__ __forceinline__ void rigid_strip_raw(const RigidArgs& a, unsigned rawrow, int m, const float* gplane,
                                                 const int (&gofs)[8], float negmu, int f, int y0, int x0, float wyv,
                                                 const float (&wx)[5][4], float (&acc)[RIGID_ROWS][4]) {
   const int h = a.h, w = a.w;
   float* orow = WRITE_FRAMES ? a.out_frames + (int64_t)f * h * w + (int64_t)y0 * w + x0 : nullptr;
-  float H[5][4];
+  rr_f2 WA[5], WB[5];  // x weights of output columns (0,1) and (2,3), per tap
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    WA[j] = rr_f2{wx[j][0], wx[j][1]};
+    WB[j] = rr_f2{wx[j][2], wx[j][3]};
+  }
+  const rr_f2 nm = {negmu, negmu};
+  rr_f2 HA[5], HB[5];  // horizontal-pass results of the last five window rows
   unsigned d[4][5];
 #pragma unroll
   for (int rr = 0; rr < RIGID_ROWS + 4; ++rr) {
@@ -1529,29 +1549,32 @@ __device__ __forceinline__ void rigid_strip_raw(const RigidArgs& a, unsigned raw
         rv[2 * j + 1] = (float)((int)wj >> 16);
       }
     }
-    float e[8];
+    float g[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) e[k] = __builtin_fmaf(rv[k], gplane[gofs[k] + rr * (4 * RR_GQ)], negmu);
-    float* Hn = H[rr % 5];
+    for (int k = 0; k < 8; ++k) g[k] = gplane[gofs[k] + rr * (4 * RR_GQ)];
+    // conditioned samples e[k] = raw * gain - mu as even pairs (e0,e1) .. (e6,e7) and the odd pairs between them
+    rr_f2 E[7];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      Hn[k] = rigid_dot5(wx[0][k], e[k], wx[1][k], e[k + 1], wx[2][k], e[k + 2], wx[3][k], e[k + 3], wx[4][k], e[k + 4]);
+    for (int i = 0; i < 4; ++i)
+      E[2 * i] = __builtin_elementwise_fma(rr_f2{rv[2 * i], rv[2 * i + 1]}, rr_f2{g[2 * i], g[2 * i + 1]}, nm);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) E[2 * i + 1] = __builtin_shufflevector(E[2 * i], E[2 * i + 2], 1, 2);
+    HA[rr % 5] = rr_dot5(WA, E[0], E[1], E[2], E[3], E[4]);
+    HB[rr % 5] = rr_dot5(WB, E[2], E[3], E[4], E[5], E[6]);
     if (rr >= 4) {
       const int ro = rr - 4;
-      float wy[5];
+      rr_f2 wy[5];
 #pragma unroll
-      for (int i = 0; i < 5; ++i)
-        wy[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wyv), ro * 5 + i));
-      float o[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        o[k] = rigid_dot5(wy[0], H[(ro + 0) % 5][k], wy[1], H[(ro + 1) % 5][k], wy[2], H[(ro + 2) % 5][k], wy[3],
-                          H[(ro + 3) % 5][k], wy[4], H[(ro + 4) % 5][k]);
+      for (int i = 0; i < 5; ++i) {
+        const float s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wyv), ro * 5 + i));
+        wy[i] = rr_f2{s, s};
+      }
+      const rr_f2 oa = rr_dot5(wy, HA[(ro + 0) % 5], HA[(ro + 1) % 5], HA[(ro + 2) % 5], HA[(ro + 3) % 5], HA[(ro + 4) % 5]);
+      const rr_f2 ob = rr_dot5(wy, HB[(ro + 0) % 5], HB[(ro + 1) % 5], HB[(ro + 2) % 5], HB[(ro + 3) % 5], HB[(ro + 4) % 5]);
       if (FULL || (y0 + ro < h && x0 < w)) {
-        if (WRITE_FRAMES) rigid_store4(orow + (int64_t)ro * w, o[0], o[1], o[2], o[3]);
+        if (WRITE_FRAMES) rigid_store4(orow + (int64_t)ro * w, oa.x, oa.y, ob.x, ob.y);
         if (WRITE_SUM) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) acc[ro][k] += o[k];
+          acc[ro][0] += oa.x; acc[ro][1] += oa.y; acc[ro][2] += ob.x; acc[ro][3] += ob.y;
         }
       }
     }
