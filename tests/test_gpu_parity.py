@@ -1665,6 +1665,27 @@ def test_fp16_frames_through_the_field_warp(mc, dev, shape, grid, ps):
     assert_frames_close(got, ref, knife, max_excluded=0.05)
 
 
+def test_field_warp_with_more_frames_than_one_plan_block(mc, dev):
+    """130 frames: the tile kernel keeps its per-frame plan entries in LDS 128 frames at a time
+    (warp.hip, warp_field3) -- frames 128, 129 come from the second block.  fp32 and fp16 frames,
+    frames and sum, against the oracle (correct_motion.py:81-185)."""
+    t, h, w = 130, 416, 512
+    g = torch.Generator().manual_seed(130)
+    st = torch.randn(t, h, w, generator=g)
+    field = torch.randn(2, 5, 2, 2, generator=g) * 2
+    ref = oracle.correct_motion(st, field, 1.0, grid_type="bspline")
+    total, frames = mc.motion_correct_sum(st.to(dev), field.to(dev), 1.0, grid_type="bspline", return_frames=True)
+    knife = knife_edge_mask(st, field, 1.0, "bspline")
+    assert_frames_close(frames, ref, knife, max_excluded=0.05)
+    assert rel_err(total, frames.sum(0)) <= 1e-5
+    only_sum = mc.motion_correct_sum(st.to(dev), field.to(dev), 1.0, grid_type="bspline")
+    assert torch.equal(only_sum, total)
+    s16, f16 = mc.motion_correct_sum(st.half().to(dev), field.to(dev), 1.0, grid_type="bspline", return_frames=True)
+    s32, f32 = mc.motion_correct_sum(st.half().float().to(dev), field.to(dev), 1.0, grid_type="bspline",
+                                     return_frames=True)
+    assert torch.equal(f16, f32) and torch.equal(s16, s32)
+
+
 # ------------------------------------------------------------------ N2: hot pixels, scattered spline points
 
 

@@ -2395,6 +2395,10 @@ __global__ __launch_bounds__(RIGID_LANES* RIGID_WAVES, GW2_MINW) void warp_field
 //  * Window origin, margins and the regularity verdict of every (tile, frame) come from a small
 //    plan kernel, so no wave ever waits for a dependent global load inside the frame loop.
 #define GW3_WAVES 16
+typedef const __attribute__((address_space(3))) float* gw3_lds_cfptr;
+#ifndef GW3_ILP
+#define GW3_ILP 1  // pixels of a lane in flight together (interior tile-frames); 1, 2 and 4 measure the same
+#endif
 #define GW3_RW (RIGID_WAVES * RIGID_ROWS / GW3_WAVES)  // pixel rows per wave (2)
 #define GW3_EROWS 6                                     // lattice rows staged per tile
 #define GW3_PLAN_MAX 128                                // frames whose plan entries are kept in LDS
@@ -2533,14 +2537,33 @@ __global__ __launch_bounds__(RIGID_LANES* GW3_WAVES, 4) void warp_field3(FieldAr
 
   // the tile's plan entries of all frames go to LDS once: a per-frame global load would put its
   // latency in front of every frame's DMA
+  // (kept in LDS GW3_PLAN_MAX frames at a time: choosing between an LDS and a global load per frame
+  // compiles to a flat load that waits for every outstanding DMA)
   __shared__ int4 s_plan[GW3_PLAN_MAX];
-  for (int i = tid; i < a.nframes && i < GW3_PLAN_MAX; i += RIGID_LANES * GW3_WAVES) s_plan[i] = plan[(int64_t)i * nt + tl];
+  auto stage_plan = [&](int f0) {
+    for (int i = tid; f0 + i < a.nframes && i < GW3_PLAN_MAX; i += RIGID_LANES * GW3_WAVES)
+      s_plan[i] = plan[(int64_t)(f0 + i) * nt + tl];
+  };
+  stage_plan(0);
   __syncthreads();
   auto fetch_plan = [&](int f) {
-    const int4 p = f < GW3_PLAN_MAX ? s_plan[f] : plan[(int64_t)f * nt + tl];
+    const int4 p = s_plan[f & (GW3_PLAN_MAX - 1)];
     return make_int4(__builtin_amdgcn_readfirstlane(p.x), __builtin_amdgcn_readfirstlane(p.y),
                      __builtin_amdgcn_readfirstlane(p.z), __builtin_amdgcn_readfirstlane(p.w));
   };
+  // The (window row, 16-byte unit) of each DMA unit this thread issues does not depend on the frame:
+  // the divisions are done once (per frame they were 13 of the kernel's 98 VALU instructions per pixel)
+  constexpr int DMA_UNITS = HALF ? GW3_STAGE_UNITS / 64 : GW_QUADS_PAD / 64;  // wave-units of 64 lanes
+  constexpr int DMA_NIT = (DMA_UNITS + GW3_WAVES - 1) / GW3_WAVES;
+  constexpr int DMA_QROW = HALF ? GW3_QH : GW_QUADS;
+  int dma_tr[DMA_NIT], dma_qc[DMA_NIT];
+#pragma unroll
+  for (int it = 0; it < DMA_NIT; ++it) {
+    const int i = wave + it * GW3_WAVES;
+    const int q = i * 64 + lane;
+    dma_tr[it] = i < DMA_UNITS ? q / DMA_QROW : 0x7fff;  // beyond the window: never issued
+    dma_qc[it] = q - (q / DMA_QROW) * DMA_QROW;
+  }
   // window + lattice rows of frame f -> LDS buffer `bi` (nothing for an irregular tile-frame)
   auto dma = [&](int f, const int4 p, int bi) {
     if (p.z >> 16) return;
@@ -2553,27 +2576,28 @@ __global__ __launch_bounds__(RIGID_LANES* GW3_WAVES, 4) void warp_field3(FieldAr
       const _Float16* frh = reinterpret_cast<const _Float16*>(a.frames) + (int64_t)f * hw;
       const int axa = p.y & ~7;
       const int nqh = (p.y - axa + RIGID_LANES * 4 + 3 + 2 * mgx + 7) / 8;  // <= GW3_QH
-      for (int i = wave; i < GW3_STAGE_UNITS / 64; i += GW3_WAVES) {
-        const int q = i * 64 + lane;
-        const int tr = q / GW3_QH, qc = q - tr * GW3_QH;
-        if (tr < nrows && qc < nqh) {
-          int r = p.x + tr;
+#pragma unroll
+      for (int it = 0; it < DMA_NIT; ++it) {
+        if (dma_tr[it] < nrows && dma_qc[it] < nqh) {
+          int r = p.x + dma_tr[it];
           r = r < 0 ? 0 : (r > h - 1 ? h - 1 : r);
-          int c = axa + 8 * qc;
+          int c = axa + 8 * dma_qc[it];
           c = c < 0 ? 0 : (c > w - 8 ? w - 8 : c);  // clamped units are never read (see widen)
-          __builtin_amdgcn_global_load_lds(frh + (int64_t)r * w + c, (lds_vptr)(stage_of(bi) + i * 64), 16, 0, 0);
+          const unsigned off = __umul24((unsigned)r, (unsigned)w) + (unsigned)c;  // h w < 2^32 (checked by the host)
+          __builtin_amdgcn_global_load_lds(frh + off, (lds_vptr)(stage_of(bi) + (wave + it * GW3_WAVES) * 64), 16, 0, 0);
         }
       }
-    } else
-    for (int i = wave; i < GW_QUADS_PAD / 64; i += GW3_WAVES) {
-      const int q = i * 64 + lane;
-      const int tr = q / GW_QUADS, qc = q - tr * GW_QUADS;
-      if (tr < nrows && qc < nq) {
-        int r = p.x + tr;
-        r = r < 0 ? 0 : (r > h - 1 ? h - 1 : r);
-        int c = p.y + 4 * qc;
-        c = c < 0 ? 0 : (c > w - 4 ? w - 4 : c);
-        __builtin_amdgcn_global_load_lds(fr + (int64_t)r * w + c, (lds_vptr)(win_of(bi) + i * 64), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int it = 0; it < DMA_NIT; ++it) {
+        if (dma_tr[it] < nrows && dma_qc[it] < nq) {
+          int r = p.x + dma_tr[it];
+          r = r < 0 ? 0 : (r > h - 1 ? h - 1 : r);
+          int c = p.y + 4 * dma_qc[it];
+          c = c < 0 ? 0 : (c > w - 4 ? w - 4 : c);
+          const unsigned off = __umul24((unsigned)r, (unsigned)w) + (unsigned)c;
+          __builtin_amdgcn_global_load_lds(fr + off, (lds_vptr)(win_of(bi) + (wave + it * GW3_WAVES) * 64), 16, 0, 0);
+        }
       }
     }
     if (wave < 2 * GW3_EROWS) {  // one 1 KiB piece per (channel, lattice row)
@@ -2617,6 +2641,11 @@ __global__ __launch_bounds__(RIGID_LANES* GW3_WAVES, 4) void warp_field3(FieldAr
     const int bi = f & 1;
     int4 pn = pc;
     if (f + 1 < a.nframes) {
+      if (((f + 1) & (GW3_PLAN_MAX - 1)) == 0) {  // next block of plan entries (every thread already holds pc)
+        __syncthreads();
+        stage_plan(f + 1);
+        __syncthreads();
+      }
       pn = fetch_plan(f + 1);
       dma(f + 1, pn, bi ^ 1);  // lands under this frame's arithmetic
     }
@@ -2643,17 +2672,99 @@ __global__ __launch_bounds__(RIGID_LANES* GW3_WAVES, 4) void warp_field3(FieldAr
       const bool interior_rt = whole_tile && wy0 >= 0 && wy0 + nrows <= h && ax >= 0 &&
                                ax + (HALF ? RIGID_LANES * 4 + 3 + 2 * mgx : 4 * nq) <= w;
       const int oy = 1 + wy0, ox = 1 + ax;
+      const unsigned tap_base = (unsigned)(uintptr_t)(lds_vptr)tile - 4u * (unsigned)(oy * GW_STRIDE + ox);
       // The tile-frame's two bodies are separate instantiations: the interior one (no zero-outside
       // test, no column predicate) is straight-line code for all of a wave's pixels, so the LDS reads
       // of one pixel are scheduled under the arithmetic of another instead of every pixel ending in an
       // exec-mask branch.
       auto pixels = [&](auto interior_tag) {
         constexpr bool interior = decltype(interior_tag)::value;
-      // One pixel at a time.  (Measured alternatives, same results, none faster: the wave's two rows
-      // statement by statement for two independent chains per lane, 3.2 ms instead of 2.96; the same
-      // on 2-float vectors, i.e. v_pk_* instructions, 3.3 ms.  The kernel is bound by VALU issue at
-      // ~1.6-2 ns per instruction -- three-source instructions whose operands share a VGPR bank take
-      // 4 cycles instead of 2, scripts/ubench/valu_banks.hip -- not by dependency latency.)
+      // What the counters say (profiles/r03_warp_field3_pmc.txt, 40 x 4092 x 5760 sum only): 87 VALU
+      // instructions per pixel at ~4.4 cycles each with 4 waves per SIMD, LDS address pipe 52 % busy.
+      // Measured alternatives, same results, none faster: 2 or 4 pixels of a lane in flight together
+      // (GW3_ILP), the wave's two rows statement by statement, the y/x sides of the chain or row pairs
+      // of the taps on 2-float vectors (a v_pk_*_f32 instruction costs 1.35-1.6 x a scalar one here,
+      // scripts/ubench/pk_rate.hip, and the pairs have to be built with moves: 3.24 ms against 2.98).
+      // Removing 11 % of the instructions (frame-invariant DMA indices, v_fract / v_cvt_flr, one tap
+      // address) bought 4 % of the time.
+      if constexpr (interior) {
+        // Interior tile-frames (all but the frame's rim): GW3_ILP pixels of a lane side by side -- their
+        // chains (shift, coordinate, weights, address) are independent, so a dependent instruction of one
+        // issues behind an instruction of the other -- then all their taps in one batch of LDS reads.
+        // Coordinates are positive here: v_fract_f32 IS u - floor(u) (exact either way) and
+        // v_cvt_flr_i32_f32 is the floor as an integer; the tap address is one 24-bit multiply-add and one
+        // shift-add from a per-frame base that holds the window origin; the 16 taps are single reads with
+        // 16-bit immediate offsets from that ONE address (paired into ds_read2_b32, whose 8-bit offsets do
+        // not reach the next window row, they cost 6 address adds per pixel).
+#pragma unroll
+        for (int r = 0; r < GW3_RW; ++r) {
+          const int y = y0 + r;
+          const int row = wave * GW3_RW + r;
+          const float4 yc4 = make_float4(s_ycoef[row][0], s_ycoef[row][1], s_ycoef[row][2], s_ycoef[row][3]);
+          const float* e0 = es + (s_ytap[row][0] - R0) * 256 + lane;
+          const float* e1 = es + (s_ytap[row][1] - R0) * 256 + lane;
+          const float* e2 = es + (s_ytap[row][2] - R0) * 256 + lane;
+          const float* e3 = es + (s_ytap[row][3] - R0) * 256 + lane;
+          float* orow = WRITE_FRAMES ? a.out_frames + (int64_t)f * hw + (int64_t)y * w + xt + lane : nullptr;
+#pragma unroll
+          for (int k0 = 0; k0 < 4; k0 += GW3_ILP) {
+            float wy[GW3_ILP][4], wx[GW3_ILP][4], tp[GW3_ILP][16];
+            gw3_lds_cfptr t0[GW3_ILP];
+#pragma unroll
+            for (int q = 0; q < GW3_ILP; ++q) {
+              const int k = k0 + q;
+              float sy = dot4(yc4, e0[64 * k], e1[64 * k], e2[64 * k], e3[64 * k]);
+              float sx = dot4(yc4, e0[64 * k + GW3_EROWS * 256], e1[64 * k + GW3_EROWS * 256],
+                              e2[64 * k + GW3_EROWS * 256], e3[64 * k + GW3_EROWS * 256]);
+              if (!UNIT_PS) {
+                sy = div_invariant(sy, a.pixel_spacing);
+                sx = div_invariant(sx, a.pixel_spacing);
+              }
+              const float uy = grid_chain((float)y + sy, fh), ux = grid_chain((float)(xt + lane + 64 * k) + sx, fw);
+              cubic_coeffs_factored(__builtin_amdgcn_fractf(uy), wy[q]);
+              cubic_coeffs_factored(__builtin_amdgcn_fractf(ux), wx[q]);
+              int iy, ix;
+              asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iy) : "v"(uy));
+              asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ix) : "v"(ux));
+              t0[q] = (gw3_lds_cfptr)(uintptr_t)(__umul24((unsigned)iy, 4u * GW_STRIDE) + tap_base + ((unsigned)ix << 2));
+            }
+#define GW3_RD(i, j) "ds_read_b32 %" #i ", %16 offset:%c" #j "\n"
+#pragma unroll
+            for (int q = 0; q < GW3_ILP; ++q)
+              asm volatile(GW3_RD(0, 17) GW3_RD(1, 18) GW3_RD(2, 19) GW3_RD(3, 20) GW3_RD(4, 21) GW3_RD(5, 22) GW3_RD(6, 23)
+                           GW3_RD(7, 24) GW3_RD(8, 25) GW3_RD(9, 26) GW3_RD(10, 27) GW3_RD(11, 28) GW3_RD(12, 29)
+                           GW3_RD(13, 30) GW3_RD(14, 31) GW3_RD(15, 32)
+                           : "=&v"(tp[q][0]), "=&v"(tp[q][1]), "=&v"(tp[q][2]), "=&v"(tp[q][3]), "=&v"(tp[q][4]),
+                             "=&v"(tp[q][5]), "=&v"(tp[q][6]), "=&v"(tp[q][7]), "=&v"(tp[q][8]), "=&v"(tp[q][9]),
+                             "=&v"(tp[q][10]), "=&v"(tp[q][11]), "=&v"(tp[q][12]), "=&v"(tp[q][13]), "=&v"(tp[q][14]),
+                             "=&v"(tp[q][15])
+                           : "v"(t0[q]), "n"(0), "n"(4), "n"(8), "n"(12), "n"(4 * GW_STRIDE), "n"(4 * GW_STRIDE + 4),
+                             "n"(4 * GW_STRIDE + 8), "n"(4 * GW_STRIDE + 12), "n"(8 * GW_STRIDE), "n"(8 * GW_STRIDE + 4),
+                             "n"(8 * GW_STRIDE + 8), "n"(8 * GW_STRIDE + 12), "n"(12 * GW_STRIDE), "n"(12 * GW_STRIDE + 4),
+                             "n"(12 * GW_STRIDE + 8), "n"(12 * GW_STRIDE + 12)
+                           : "memory");
+#undef GW3_RD
+            // one wait for the batch; the operand lists tie every tap to it
+#pragma unroll
+            for (int q = 0; q < GW3_ILP; ++q)
+              asm volatile("s_waitcnt lgkmcnt(0)"
+                           : "+v"(tp[q][0]), "+v"(tp[q][1]), "+v"(tp[q][2]), "+v"(tp[q][3]), "+v"(tp[q][4]), "+v"(tp[q][5]),
+                             "+v"(tp[q][6]), "+v"(tp[q][7]), "+v"(tp[q][8]), "+v"(tp[q][9]), "+v"(tp[q][10]),
+                             "+v"(tp[q][11]), "+v"(tp[q][12]), "+v"(tp[q][13]), "+v"(tp[q][14]), "+v"(tp[q][15])
+                           :: "memory");
+#pragma unroll
+            for (int q = 0; q < GW3_ILP; ++q) {
+              float rowv[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                rowv[i] = gw_dot4(wx[q], tp[q][4 * i], tp[q][4 * i + 1], tp[q][4 * i + 2], tp[q][4 * i + 3]);
+              const float o = gw_dot4(wy[q], rowv[0], rowv[1], rowv[2], rowv[3]);
+              if (WRITE_FRAMES) orow[64 * (k0 + q)] = o;
+              if (WRITE_SUM) acc[r][k0 + q] += o;
+            }
+          }
+        }
+      } else
 #pragma unroll
       for (int r = 0; r < GW3_RW; ++r) {
         const int y = y0 + r;
@@ -2678,21 +2789,18 @@ __global__ __launch_bounds__(RIGID_LANES* GW3_WAVES, 4) void warp_field3(FieldAr
           }
           const float cy = (float)y + sy, cx = (float)x + sx;
           const float uy = grid_chain(cy, fh), ux = grid_chain(cx, fw);
-          const float fy = floorf(uy), fx = floorf(ux);
           float wy[4], wx[4];
+          float rowv[4];
+          const float fy = floorf(uy), fx = floorf(ux);
           cubic_coeffs_factored(uy - fy, wy);
           cubic_coeffs_factored(ux - fx, wx);
           int ly = (int)fy - oy, lx = (int)fx - ox;
-          bool inside = true;
-          if (!interior) {
-            inside = (cy >= 0.f) && (cy <= fh - 1.f) && (cx >= 0.f) && (cx <= fw - 1.f);
-            // in range by the regularity test; the clamp only keeps a garbage coordinate from
-            // reading outside the LDS tile
-            ly = ly < 0 ? 0 : (ly > GW_ROWS - 4 ? GW_ROWS - 4 : ly);
-            lx = lx < 0 ? 0 : (lx > GW_STRIDE - 4 ? GW_STRIDE - 4 : lx);
-          }
+          const bool inside = (cy >= 0.f) && (cy <= fh - 1.f) && (cx >= 0.f) && (cx <= fw - 1.f);
+          // in range by the regularity test; the clamp only keeps a garbage coordinate from
+          // reading outside the LDS tile
+          ly = ly < 0 ? 0 : (ly > GW_ROWS - 4 ? GW_ROWS - 4 : ly);
+          lx = lx < 0 ? 0 : (lx > GW_STRIDE - 4 ? GW_STRIDE - 4 : lx);
           const float* t0 = tile + ly * GW_STRIDE + lx;
-          float rowv[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const float* t = t0 + i * GW_STRIDE;
@@ -3003,7 +3111,9 @@ int mc_warp_frames_t(const void* frames_any, int storage, int nframes, int h, in
 #endif
     // version 3 stages <= GW3_EROWS lattice rows per tile: 32 pixel rows must span <= 1.5 lattice
     // cells (always for the reference's 10 nodes per patch; not for a per-pixel lattice)
-    if ((field_version == 3 || half) && (int64_t)32 * (GH - 1) * 2 <= (int64_t)3 * (h - 1)) {
+    // (warp_field3 addresses a frame with 32-bit element offsets built by 24-bit multiplies)
+    const bool small32 = h < (1 << 24) && w < (1 << 24) && (int64_t)h * w < ((int64_t)1 << 31);
+    if ((field_version == 3 || half) && small32 && (int64_t)32 * (GH - 1) * 2 <= (int64_t)3 * (h - 1)) {
       int4* plan = reinterpret_cast<int4*>(fa.flags + field_flag_bytes(nframes, h, w));
       hipLaunchKernelGGL(warp_field_plan, dim3(a.tiles_x * a.tiles_y, nframes), dim3(64), 0, s, fa, unit ? 1 : 0,
                          half ? 1 : 0, plan);

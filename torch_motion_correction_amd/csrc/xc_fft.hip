@@ -1183,7 +1183,9 @@ __global__ __launch_bounds__(MC_WG) void xc_cols_inv(
 // registers over its columns, then one float atomic per (thread, row).  The full map is
 // only ever materialised (xc_cols_inv, gated by `need_full`) when some far row's bound
 // reaches the maximum found in the near window.
+#ifndef XC_NEAR_COLS
 #define XC_NEAR_COLS 8
+#endif
 #define XC_NEAR_GUARD 8  // extra stored rows per end: neighbourhood of a peak on the window's edge
 template <int LOGH, bool R16 = false>
 __global__ __launch_bounds__(MC_WG) void xc_cols_inv_near(
