@@ -148,6 +148,12 @@ int mc_xc_rows_forward_dual_t(const void* src, int storage, const int64_t* job_o
  * 1 = always the radix-8 Stockham passes.  Process-wide; results agree to fp32 rounding. */
 int mc_xc_col_engine(int mode);
 
+/* Scheduling aid for a caller that overlaps movies on several streams (pipeline.py): while `event`
+ * (a hipEvent_t) is non-NULL, mc_xc_correlate_argmax records it on its stream right after the
+ * near-window column pass -- the last kernel of the search that fills the machine.  Process-wide;
+ * NULL switches it off.  No effect on results. */
+int mc_xc_after_k3n_event(void* event);
+
 /* Row-transform engine of K1: 0 = automatic (W == 4096, nkx <= 512, no per-job exponents,
  * 16-byte aligned src/mask and row_stride % 4 == 0 -> one wavefront per row, mc_wave_fft.h;
  * job_off[] must then be multiples of 4 floats, as whole-frame offsets f*h*w are),

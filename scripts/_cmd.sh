@@ -1,3 +1,7 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests -x -q -m gpu -k "warp or field or correct or fp16 or sum" > gpurun_out/e26_tests.txt 2>&1; echo "rc=$?" >> gpurun_out/e26_tests.txt; tail -5 gpurun_out/e26_tests.txt
-python scripts/field_warp_time.py 2>&1 | grep -v amdgpu.ids
+for tag in base hyp1; do
+  if [ $tag = base ]; then export MCORR_LIB=$PWD/torch_motion_correction_amd/libmcorr.so; else export MCORR_LIB=$PWD/variants/$tag/libmcorr.so; fi
+  echo "== $tag"
+  bash scripts/gpu_prof_py.sh k3n_$tag scripts/k3n_time.py 2>&1 | grep -v amdgpu.ids | grep "cols_inv_near" || exit 1
+  python scripts/far_margin.py 4.0 2>&1 | grep "noise"
+done

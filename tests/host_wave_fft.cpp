@@ -97,8 +97,33 @@ static double run(unsigned seed, int x0, int x1) {
   return worst / scale;
 }
 
+// wf_dft16_lo2 (inputs 2..13 zero, the band-passed columns of the search) against wf_dft16 on the same data
+static double run_lo2(unsigned seed) {
+  srand(seed);
+  double worst = 0.0, scale = 0.0;
+  for (int trial = 0; trial < 64; ++trial) {
+    wf2 a[16], b[16];
+    for (int i = 0; i < 16; ++i) {
+      const bool kept = i < 2 || i >= 14;
+      a[i] = kept ? wf_make((float)(rand() % 65536) / 65536.f - 0.5f, (float)(rand() % 65536) / 65536.f - 0.5f)
+                  : wf_make(0.f, 0.f);
+      b[i] = a[i];
+    }
+    wf_dft16(a);
+    wf_dft16_lo2(b);
+    for (int i = 0; i < 16; ++i) {
+      worst = fmax(worst, fmax(fabs((double)a[i].x - b[i].x), fabs((double)a[i].y - b[i].y)));
+      scale = fmax(scale, fmax(fabs((double)a[i].x), fabs((double)a[i].y)));
+    }
+  }
+  return worst / scale;
+}
+
 int main() {
   int bad = 0;
+  const double e0 = run_lo2(7);
+  printf("wf_dft16_lo2 against wf_dft16: %.3g\n", e0);
+  if (!(e0 < 5e-7)) bad = 1;
   const double e1 = run<1>(1, 0, 4096), e2 = run<2>(2, 0, 4096), e3 = run<2>(3, 510, 3586);
   printf("relative error KEEP=1: %.3g  KEEP=2: %.3g  KEEP=2 (support 510..3586): %.3g\n", e1, e2, e3);
   if (!(e1 < 2e-6) || !(e2 < 2e-6) || !(e3 < 2e-6)) bad = 1;

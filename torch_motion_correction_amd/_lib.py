@@ -48,6 +48,7 @@ SIGNATURES = {
     "mc_xc_rows_lds_bytes": [GP],
     "mc_xc_row_engine": [i32],
     "mc_xc_col_engine": [i32],
+    "mc_xc_after_k3n_event": [vp],
     "mc_xc_rows_forward": [vp, vp, i64, vp, vp, vp, vp, vp, i32, GP, vp],
     "mc_xc_rows_forward_dual": [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, GP, vp, vp],
     "mc_xc_rows_forward_dual_t": [vp, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, GP, vp, vp],

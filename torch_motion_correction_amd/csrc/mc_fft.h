@@ -691,7 +691,8 @@ __device__ __forceinline__ void wg_fft4096_r16(cfloat* line_c, int tid, const cf
     if (n1 < IN_KEEP || n1 >= 16 - IN_KEEP) a[n1] = cj(wf_from(load(n1, 256 * n1 + tid)));
     else a[n1] = wf2{0.f, 0.f};
   }
-  wf_dft16(a);
+  if constexpr (IN_KEEP == 2) wf_dft16_lo2(a);  // 12 of the 16 inputs are zero
+  else wf_dft16(a);
   {
     const wf2 w1 = twp(tid), w2 = twp(2 * tid), w4 = twp(4 * tid), w8 = twp(8 * tid);  // exact bases
     const wf2 w3 = wf_cmul(w2, w1), w5 = wf_cmul(w4, w1), w6 = wf_cmul(w4, w2), w7 = wf_cmul(w4, w3);

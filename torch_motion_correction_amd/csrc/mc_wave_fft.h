@@ -144,6 +144,52 @@ MC_HD void wf_dft16(wf2 (&a)[16]) {
     }
 }
 
+// wf_dft16 of an input whose entries 2..13 are zero (a column of a band-passed spectrum: of the 16
+// interleaved sub-sequences of pass A only the rows |ky| < 512 of 4096 carry data).  Every column j of
+// the 4 x 4 decomposition then has ONE non-zero input, so its 4-point DFT is that input times W_4^{m p}
+// (m = 0 for j = 0, 1: all four outputs equal it; m = 3 for j = 2, 3: x, i x, -x, -i x) and the whole
+// first stage folds into the W_16 twiddles: 9 constant complex multiplies instead of 4 butterflies + 9.
+MC_HD void wf_dft16_lo2(wf2 (&a)[16]) {
+  const float C1 = 0.92387953251128673848f, S1 = 0.38268343236508978178f;
+  const float H = 0.70710678118654752440f;
+  const wf2 x0 = a[0], x1 = a[1], x2 = a[14], x3 = a[15];
+  a[0] = x0; a[4] = x0; a[8] = x0; a[12] = x0;
+  a[1] = x1;
+  a[1 + 4] = wf_cmulc(x1, C1, -S1);   // W^1
+  a[1 + 8] = wf_cmulc(x1, H, -H);     // W^2
+  a[1 + 12] = wf_cmulc(x1, S1, -C1);  // W^3
+  a[2] = x2;
+  a[2 + 4] = wf_cmulc(x2, H, H);      // i W^2
+  a[2 + 8] = -x2;                     // (-1); W^4 = -i is folded into the second stage as in wf_dft16
+  a[2 + 12] = wf_cmulc(x2, -H, H);    // -i W^6
+  a[3] = x3;
+  a[3 + 4] = wf_cmulc(x3, C1, S1);    // i W^3
+  a[3 + 8] = wf_cmulc(x3, H, H);      // -W^6
+  a[3 + 12] = wf_cmulc(x3, S1, C1);   // -i W^9
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    wf2 &b0 = a[4 * p], &b1 = a[4 * p + 1], &b2 = a[4 * p + 2], &b3 = a[4 * p + 3];
+    if (p == 2) {  // b2 stands for -i b2
+      const wf2 t0 = wf_add_mi(b0, b2), t1 = wf_sub_mi(b0, b2);
+      const wf2 t2 = b1 + b3, d = b1 - b3;
+      b0 = t0 + t2;
+      b2 = t0 - t2;
+      b1 = wf_add_mi(t1, d);
+      b3 = wf_sub_mi(t1, d);
+    } else {
+      wf_bfly4(b0, b1, b2, b3);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int r = p + 1; r < 4; ++r) {
+      const wf2 s = a[4 * p + r];
+      a[4 * p + r] = a[4 * r + p];
+      a[4 * r + p] = s;
+    }
+}
+
 // forward 8-point DFT, natural order in (e = even inputs n3 = 0,2,4,6; o = odd inputs
 // 1,3,5,7); only outputs 0, 1, 6, 7 (KEEP = 2) or 0, 7 (KEEP = 1) are produced
 template <int KEEP>

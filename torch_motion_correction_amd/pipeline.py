@@ -113,10 +113,13 @@ class MoviePipeline:
             yield from self._iterate_three_stage(movies, call, caller)
             return
         sched = os.environ.get("MC_PIPE_SCHEDULE", "k1first")
-        k1_first = sched in ("k1first", "k2first")
+        k1_first = sched in ("k1first", "k2first", "k3first")
         engine.HOOK_AFTER_K2 = sched == "k2first"
+        from . import _lib
+        lib = _lib.load()
         try:
             pending = None  # k1first: (img, field, tables, ready) of the movie whose warp is not enqueued yet
+            warp_done = None
             for img in movies:
                 with device_scope(dev):
                     img = self._check(img)
@@ -124,12 +127,23 @@ class MoviePipeline:
                     img.record_stream(self._s_warp)
                     k1_done = torch.cuda.Event() if k1_first else None
                     with torch.cuda.stream(self._s_est):
-                        if k1_first:
+                        if sched == "k3first":
+                            # the previous warp waits until every machine-filling kernel of this estimate (K1,
+                            # K2, the near-window column pass) has run; the C library records the event.  And
+                            # this estimate starts once the warp before that one has finished: strict alternation
+                            # [K1 K2 K3n](k+1) -> [warp(k) || rest of the search(k+1)] -> [K1 K2 K3n](k+2) ...
+                            if warp_done is not None:
+                                self._s_est.wait_event(warp_done)
+                            k1_done.record(self._s_est)  # creates the hipEvent
+                            lib.mc_xc_after_k3n_event(k1_done.cuda_event)
+                        elif k1_first:
                             engine.AFTER_K1_HOOK = lambda: k1_done.record(self._s_est)
                         try:
                             field = self._estimate(img)
                         finally:
                             engine.AFTER_K1_HOOK = None
+                            if sched == "k3first":
+                                lib.mc_xc_after_k3n_event(None)
                         tables = self._prepare(img, field)
                         ready = torch.cuda.Event()
                         ready.record(self._s_est)
@@ -154,6 +168,9 @@ class MoviePipeline:
                             pimg, pfield, ptables, pready = pending
                             frames, total = enqueue_warp(pimg, pfield, ptables, pready, k1_done)
                             res = MovieResult(pfield, total, frames)
+                            if sched == "k3first":
+                                warp_done = torch.cuda.Event()
+                                warp_done.record(self._s_warp)
                         pending = (img, field, tables, ready)
                 if res is not None:
                     yield res
