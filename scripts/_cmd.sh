@@ -1,7 +1,8 @@
 cd $GRAFT_REPO_ROOT
-for tag in base hyp1; do
-  if [ $tag = base ]; then export MCORR_LIB=$PWD/torch_motion_correction_amd/libmcorr.so; else export MCORR_LIB=$PWD/variants/$tag/libmcorr.so; fi
-  echo "== $tag"
-  bash scripts/gpu_prof_py.sh k3n_$tag scripts/k3n_time.py 2>&1 | grep -v amdgpu.ids | grep "cols_inv_near" || exit 1
-  python scripts/far_margin.py 4.0 2>&1 | grep "noise"
-done
+timeout -k 10 900 python -m pytest tests -x -q -m gpu -k "global or estimate or shifts or pipeline or raw or smoke or patch or k3 or size" > gpurun_out/e28_tests.txt 2>&1; tail -3 gpurun_out/e28_tests.txt
+for s in 1 2; do python bench.py --steps 40 --warmup 5 --no-secondary --no-cpu-baseline 2>&1 | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); print(d['ms_per_step'], d['value'], d['roofline']['frac'], d['roofline']['ms_per_launch'], d['roofline'].get('whole_step_frac'), d['config'].get('shifts_match_ground_truth'))
+"; done

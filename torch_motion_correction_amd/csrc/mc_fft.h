@@ -678,12 +678,34 @@ __device__ __forceinline__ void wg_bluestein(cfloat* line, int tid, const cfloat
 // =====================================================================================
 #include "mc_wave_fft.h"
 
+// The eight twiddle bases a thread needs (exact table entries; the other 22 are products): they depend on
+// the thread index only, so a kernel that transforms many lines per workgroup loads them once
+// (r16_twiddles) instead of waiting for eight global loads in the middle of every line.
+struct R16Tw {
+  wf2 a1, a2, a4, a8, b1, b2, b4, b8;
+};
+__device__ __forceinline__ R16Tw r16_twiddles(int tid, const cfloat* __restrict__ tw) {
+  const int n3 = tid & 15;
+  R16Tw t;
+  t.a1 = wf_from(tw[tid]); t.a2 = wf_from(tw[2 * tid]); t.a4 = wf_from(tw[4 * tid]); t.a8 = wf_from(tw[8 * tid]);
+  t.b1 = wf_from(tw[16 * n3]); t.b2 = wf_from(tw[32 * n3]); t.b4 = wf_from(tw[64 * n3]); t.b8 = wf_from(tw[128 * n3]);
+  return t;
+}
+
+template <int DIR, int IN_KEEP, int OUT_KEEP, typename Load, typename Store>
+__device__ __forceinline__ void wg_fft4096_r16_tw(cfloat* line_c, int tid, const R16Tw& TW, Load load, Store store);
+
 template <int DIR, int IN_KEEP, int OUT_KEEP, typename Load, typename Store>
 __device__ __forceinline__ void wg_fft4096_r16(cfloat* line_c, int tid, const cfloat* __restrict__ tw,
                                                Load load, Store store) {
+  const R16Tw TW = r16_twiddles(tid, tw);
+  wg_fft4096_r16_tw<DIR, IN_KEEP, OUT_KEEP>(line_c, tid, TW, load, store);
+}
+
+template <int DIR, int IN_KEEP, int OUT_KEEP, typename Load, typename Store>
+__device__ __forceinline__ void wg_fft4096_r16_tw(cfloat* line_c, int tid, const R16Tw& TW, Load load, Store store) {
   wf2* line = reinterpret_cast<wf2*>(line_c);
   auto cj = [](wf2 v) { return DIR > 0 ? wf2{v.x, -v.y} : v; };
-  auto twp = [&](int k) { return wf_from(tw[k]); };
   wf2 a[16];
   // ---- pass A
 #pragma unroll
@@ -694,7 +716,7 @@ __device__ __forceinline__ void wg_fft4096_r16(cfloat* line_c, int tid, const cf
   if constexpr (IN_KEEP == 2) wf_dft16_lo2(a);  // 12 of the 16 inputs are zero
   else wf_dft16(a);
   {
-    const wf2 w1 = twp(tid), w2 = twp(2 * tid), w4 = twp(4 * tid), w8 = twp(8 * tid);  // exact bases
+    const wf2 w1 = TW.a1, w2 = TW.a2, w4 = TW.a4, w8 = TW.a8;  // exact bases
     const wf2 w3 = wf_cmul(w2, w1), w5 = wf_cmul(w4, w1), w6 = wf_cmul(w4, w2), w7 = wf_cmul(w4, w3);
     a[1] = wf_cmul(a[1], w1); a[2] = wf_cmul(a[2], w2); a[3] = wf_cmul(a[3], w3); a[4] = wf_cmul(a[4], w4);
     a[5] = wf_cmul(a[5], w5); a[6] = wf_cmul(a[6], w6); a[7] = wf_cmul(a[7], w7); a[8] = wf_cmul(a[8], w8);
@@ -713,7 +735,7 @@ __device__ __forceinline__ void wg_fft4096_r16(cfloat* line_c, int tid, const cf
     for (int n2 = 0; n2 < 16; ++n2) a[n2] = line[k1 * 256 + ((16 * n2 + n3) ^ (16 * (k1 & 1)))];
     __syncthreads();  // everyone has read exchange 1 before exchange 2 overwrites the line
     wf_dft16(a);
-    const wf2 w1 = twp(16 * n3), w2 = twp(32 * n3), w4 = twp(64 * n3), w8 = twp(128 * n3);
+    const wf2 w1 = TW.b1, w2 = TW.b2, w4 = TW.b4, w8 = TW.b8;
     const wf2 w3 = wf_cmul(w2, w1), w5 = wf_cmul(w4, w1), w6 = wf_cmul(w4, w2), w7 = wf_cmul(w4, w3);
     a[1] = wf_cmul(a[1], w1); a[2] = wf_cmul(a[2], w2); a[3] = wf_cmul(a[3], w3); a[4] = wf_cmul(a[4], w4);
     a[5] = wf_cmul(a[5], w5); a[6] = wf_cmul(a[6], w6); a[7] = wf_cmul(a[7], w7); a[8] = wf_cmul(a[8], w8);
@@ -733,6 +755,10 @@ __device__ __forceinline__ void wg_fft4096_r16(cfloat* line_c, int tid, const cf
     wf_dft16(a);
 #pragma unroll
     for (int k3 = 0; k3 < 16; ++k3)
-      if (k3 < OUT_KEEP || k3 >= 16 - OUT_KEEP) store(tid + 256 * k3, wf_to(cj(a[k3])));
+      if (k3 < OUT_KEEP || k3 >= 16 - OUT_KEEP) {
+        // a store that takes the (compile-time) butterfly output index first can keep per-output data in registers
+        if constexpr (std::is_invocable_v<Store, int, int, cfloat>) store(k3, tid + 256 * k3, wf_to(cj(a[k3])));
+        else store(tid + 256 * k3, wf_to(cj(a[k3])));
+      }
   }
 }

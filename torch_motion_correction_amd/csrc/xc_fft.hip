@@ -837,7 +837,9 @@ __global__ void xc_stats_finalize(const double* __restrict__ acc_slots, double c
 // ------------------------------------------------------------------ K2: columns forward
 // fix (optional): {dmean, rstd} and Mhat = pruned spectrum of the mask: the spectrum of
 // ((x - m0) - dmean) * rstd * mask is (Y - dmean * Mhat) * rstd by linearity.
-#define XC_FWD_COLS 1  // columns per workgroup in the radix-16 K2 (4 with prefetch measured slower: 170 vs 154 us)
+#ifndef XC_FWD_COLS
+#define XC_FWD_COLS 2  // columns per workgroup in the radix-16 K2, the second one fetched under the first (1: 107, 2: 101, 4: 105 us)
+#endif
 // R16 (H = 4096, kyp and kyn <= 512): the register-resident radix-16 transform of mc_fft.h
 // with the unwanted output rows pruned at compile time.
 template <int LOGH, bool R16 = false>
@@ -887,6 +889,12 @@ __global__ __launch_bounds__(MC_WG) void xc_cols_fwd(const cfloat* __restrict__ 
     };
     cfloat curv[16], nxtv[16];
     fetch(kx0 < g.nkx ? kx0 : g.nkx - 1, curv, tid);
+    // twiddle bases and (below) the filter / mask-spectrum values of the 4 rows this thread stores: all issued with
+    // the column's samples, instead of waiting for them in the middle and at the end of the transform
+    const R16Tw TW = r16_twiddles(tid, tw_col);
+    int kyo[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) kyo[s4] = kept_index(tid + 256 * (s4 < 2 ? s4 : s4 + 12), H, g.kyp, g.kyn);
 #pragma unroll 1
     for (int cc = 0; cc < XC_FWD_COLS; ++cc) {
       const int kxc = kx0 + cc;
@@ -898,19 +906,21 @@ __global__ __launch_bounds__(MC_WG) void xc_cols_fwd(const cfloat* __restrict__ 
       const float* fc = filt ? filt + (int64_t)kxc * nky : nullptr;
       const cfloat* mhc = fix ? Mhat + (int64_t)kxc * nky : nullptr;
       auto loadr = [&](int n1, int) { return curv[n1]; };
-      auto storer = [&](int ky, cfloat v) {
-        int kyi = -1;
-        if (ky < g.kyp) kyi = ky;
-        else if (ky >= H - g.kyn) kyi = ky - (H - g.kyn) + g.kyp;
-        if (kyi >= 0) {
-          if (fix) {
-            const cfloat m = mhc[kyi];
-            v = cmake((v.x - dmean * m.x) * rstd, (v.y - dmean * m.y) * rstd);
-          }
-          outc[kyi] = fc ? cscale(v, fc[kyi]) : v;
+      float fpre[4];
+      cfloat mpre[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        fpre[s4] = (fc && kyo[s4] >= 0) ? fc[kyo[s4]] : 1.f;
+        mpre[s4] = (fix && kyo[s4] >= 0) ? mhc[kyo[s4]] : cmake(0.f, 0.f);
+      }
+      auto storer = [&](int k3, int, cfloat v) {  // k3 in {0, 1, 14, 15}, a compile-time constant at every call
+        const int s4 = k3 < 2 ? k3 : k3 - 12;
+        if (kyo[s4] >= 0) {
+          if (fix) v = cmake((v.x - dmean * mpre[s4].x) * rstd, (v.y - dmean * mpre[s4].y) * rstd);
+          outc[kyo[s4]] = fc ? cscale(v, fpre[s4]) : v;
         }
       };
-      wg_fft4096_r16<-1, 8, 2>(line, tcol, tw_col, loadr, storer);
+      wg_fft4096_r16_tw<-1, 8, 2>(line, tcol, TW, loadr, storer);
       __syncthreads();
 #pragma unroll
       for (int n1 = 0; n1 < 16; ++n1) curv[n1] = nxtv[n1];
@@ -1203,12 +1213,34 @@ __global__ __launch_bounds__(MC_WG) void xc_cols_inv_near(
   float acc[NOUT];
 #pragma unroll
   for (int c = 0; c < NOUT; ++c) acc[c] = 0.f;
+  const int64_t cur_base = (int64_t)cur_idx[p] * g.nkx, ref_base = (int64_t)ref_idx[p] * g.nkx;
+  // R16: a thread's pass-A inputs are rows tid + 256 n1, n1 in {0, 1, 14, 15} (the band-pass keeps |ky| < 512);
+  // the next column's eight values are fetched while this column is transformed (its loads used to sit, exposed,
+  // at the head of every column: the kernel is neither VALU- nor HBM-bound, profiles/r03_k3n_pmc.txt)
+  int kyi4[4];
+  cfloat pc[4], pr[4];
+  auto fetch4 = [&](int kx, cfloat (&c4)[4], cfloat (&r4)[4]) {
+    const cfloat* cur = S_cur + (cur_base + kx) * nky;
+    const cfloat* ref = S_ref + (ref_base + kx) * nky;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      c4[s4] = kyi4[s4] >= 0 ? cur[kyi4[s4]] : cmake(0.f, 0.f);
+      r4[s4] = kyi4[s4] >= 0 ? ref[kyi4[s4]] : cmake(0.f, 0.f);
+    }
+  };
+  R16Tw TW;  // twiddle bases: once per workgroup, not eight global loads inside every column
+  if constexpr (R16) {
+    TW = r16_twiddles(tid, tw_col);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) kyi4[s4] = kept_index(tid + 256 * (s4 < 2 ? s4 : s4 + 12), H, g.kyp, g.kyn);
+    if ((int)blockIdx.x * XC_NEAR_COLS < g.nkx) fetch4(blockIdx.x * XC_NEAR_COLS, pc, pr);
+  }
 #pragma unroll 1
   for (int cc = 0; cc < XC_NEAR_COLS; ++cc) {
     const int kx = blockIdx.x * XC_NEAR_COLS + cc;
     if (kx >= g.nkx) break;  // workgroup-uniform
-    const cfloat* cur = S_cur + ((int64_t)cur_idx[p] * g.nkx + kx) * nky;
-    const cfloat* ref = S_ref + ((int64_t)ref_idx[p] * g.nkx + kx) * nky;
+    const cfloat* cur = S_cur + (cur_base + kx) * nky;
+    const cfloat* ref = S_ref + (ref_base + kx) * nky;
     cfloat* outn = T2n + ((int64_t)p * g.nkx + kx) * (2 * nstore);
     const float wgt = kx == 0 ? 1.f : 2.f;
     auto load = [&](int ky) {
@@ -1216,7 +1248,16 @@ __global__ __launch_bounds__(MC_WG) void xc_cols_inv_near(
       if (kyi < 0) return cmake(0.f, 0.f);
       return cscale(cmulc(ref[kyi], cur[kyi]), scale);
     };
-    auto load16 = [&](int, int ky) { return load(ky); };
+    cfloat qc[4], qr[4];  // this column's values; pc / pr receive the next column's
+    if constexpr (R16) {
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        qc[s4] = pc[s4];
+        qr[s4] = pr[s4];
+      }
+      if (cc + 1 < XC_NEAR_COLS && kx + 1 < g.nkx) fetch4(kx + 1, pc, pr);
+    }
+    auto load16 = [&](int n1, int) { return cscale(cmulc(qr[n1 < 2 ? n1 : n1 - 12], qc[n1 < 2 ? n1 : n1 - 12]), scale); };
     int c = 0;
     auto store = [&](int y, cfloat v) {
       const int yn = y < nstore ? y : y - (H - 2 * nstore);  // position in the stored window
@@ -1235,7 +1276,7 @@ __global__ __launch_bounds__(MC_WG) void xc_cols_inv_near(
     // first and the last of a thread's 16 rows tid + 256 k3 can lie in the window -- 14 tests fold away)
     __builtin_assume(tcol >= 0 && tcol < MC_WG);
     __builtin_assume(nstore > 0 && nstore <= 256);
-    if constexpr (R16) wg_fft4096_r16<+1, 2, 8>(line, tcol, tw_col, load16, store);
+    if constexpr (R16) wg_fft4096_r16_tw<+1, 2, 8>(line, tcol, TW, load16, store);
     else wg_fft<H, +1>(line, tcol, tw_col, 1, load, store);
     __syncthreads();  // the next column's first pass overwrites the line
   }
