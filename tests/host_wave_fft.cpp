@@ -34,10 +34,9 @@ static double run(unsigned seed, int x0, int x1) {
     }
     wf_dft16(A0[t]);
     wf_dft16(A1[t]);
-    for (int k1 = 1; k1 < 16; ++k1) {  // twA[k1 - 1][q] = W_2048^{q k1} = tw4096(2 q k1)
-      A0[t][k1] = wf_cmul(A0[t][k1], tw4096(2 * (2 * t) * k1));
-      A1[t][k1] = wf_cmul(A1[t][k1], tw4096(2 * (2 * t + 1) * k1));
-    }
+    // twA[s][q] = W_2048^{q 2^s} = tw4096(2 q 2^s): the four exact bases, the other eleven are products
+    wf_twiddle16(A0[t], tw4096(2 * (2 * t)), tw4096(4 * (2 * t)), tw4096(8 * (2 * t)), tw4096(16 * (2 * t)));
+    wf_twiddle16(A1[t], tw4096(2 * (2 * t + 1)), tw4096(4 * (2 * t + 1)), tw4096(8 * (2 * t + 1)), tw4096(16 * (2 * t + 1)));
   }
   // exchange 1, pass B
   for (int h = 0; h < 2; ++h) {

@@ -184,15 +184,28 @@ __device__ __forceinline__ void wf_pin(int& v, float dep) { asm volatile("" : "+
 #define XC_STAT_SLOTS 64  // stats_acc = XC_STAT_SLOTS x {sum, sumsq} doubles
 
 // Twiddles come from two LDS tables shared by the workgroup's four waves (filled once from
-// tw_row, exact table values instead of products of a base twiddle):
-//   twA[k1 - 1][q]       = W_2048^{q k1}        k1 = 1..15, q < 128   (15 KiB)
+// tw_row, exact table values):
+//   twA[s][q]            = W_2048^{q 2^s}        s = 0..3, q < 128     (4 KiB)
 //   twB[g][k2 - 1][h]    = W_128^{(2 g + h) k2}  k2 = 1..15            (960 B)
-// Lane t reads twA[k1-1][2t..2t+1] and twB[t>>4][k2-1][0..1] as one 16-byte LDS read each
-// (the latter a broadcast within 16 lanes).
-#define WF_TWA (15 * 128)
+// Lane t reads twA[s][2t..2t+1] and twB[t>>4][k2-1][0..1] as one 16-byte LDS read each
+// (the latter a broadcast within 16 lanes).  Pass A's fifteen twiddles W^{q k1} are the four exact
+// bases k1 = 1, 2, 4, 8 and eleven products of them (wf_twiddle16, as the 1024- and 4096-point column
+// engines do): the table of all fifteen was 15 KiB, and with it a workgroup's 51 KB of LDS allowed three
+// workgroups per CU; 40 KB allow four.  The kernel is bound by how many waves are there to issue (49 %
+// VALU, 37 % LDS, 62 % of the HBM ceiling; a wave issues at most one VALU instruction per ~6 cycles,
+// scripts/ubench/pk_rate.hip), so the fourth wave per SIMD is worth more than the 44 extra instructions
+// per row.
+#define WF_TWA (4 * 128)
 #define WF_TWB (4 * 15 * 2)
-#define WF_ROWS_PER_WG 16  // 4 rows (two pairs) per wave
+#ifndef WF_ROWS_PER_WG
+#define WF_ROWS_PER_WG 16  // rounds of 8 rows: a wave takes rows 2 wv and 2 wv + 1 of every round
+#endif
+#ifndef WF_PREFETCH_DEFAULT
 #define WF_PREFETCH_DEFAULT 1  // 1: next row's samples, 2: and mask row, loaded under the current transform
+#endif
+#ifndef WF_MIN_WG
+#define WF_MIN_WG 2  // workgroups per CU the register allocation aims at (2: 256 VGPRs per lane, 3: 168)
+#endif
 
 // N1LO / N1HI: only the 256-sample chunks [N1LO, N1HI) of a row can touch the mask support,
 // the others are zero and are not loaded.  CLAMP_ALL = false: the chunks strictly between
@@ -249,7 +262,11 @@ template <int N1LO, int N1HI>
 __device__ __forceinline__ void wf_load_mask(const float* __restrict__ mrow, int t, float4 (&mk)[16]) {
   // mask rows (L2-resident) are read as they are: exact zeros outside the support
 #pragma unroll
+#ifdef MC_K1_NOMASK  // timing experiment only (wrong results): what the mask loads cost
+  for (int n1 = N1LO; n1 < N1HI; ++n1) mk[n1] = make_float4(1.f, 1.f, 1.f, 1.f);
+#else
   for (int n1 = N1LO; n1 < N1HI; ++n1) mk[n1] = *reinterpret_cast<const float4*>(mrow + 256 * n1 + 4 * t);
+#endif
 }
 
 // One row.  PREFETCH 0: px / mk are loaded here.  1: px holds this row's samples on entry
@@ -372,16 +389,13 @@ __device__ __forceinline__ void wf_row(float4 (&px)[16], float4 (&mk)[16],
   wf_dft16(A0);
   wf_pin(tl, A0[15].y);  // table reads fly under the second butterfly
   {
-    const float4* twa = reinterpret_cast<const float4*>(twA) + tl;  // [k1-1][64 lanes] of 16 B
-    float4 w[15];
+    const float4* twa = reinterpret_cast<const float4*>(twA) + tl;  // [s][64 lanes] of 16 B: q = 2 t, 2 t + 1
+    float4 w[4];
 #pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) w[k1 - 1] = twa[(k1 - 1) * 64];
+    for (int sb = 0; sb < 4; ++sb) w[sb] = twa[sb * 64];
     wf_dft16(A1);
-#pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) {
-      A0[k1] = wf_cmul(A0[k1], wf2{w[k1 - 1].x, w[k1 - 1].y});
-      A1[k1] = wf_cmul(A1[k1], wf2{w[k1 - 1].z, w[k1 - 1].w});
-    }
+    wf_twiddle16(A0, wf2{w[0].x, w[0].y}, wf2{w[1].x, w[1].y}, wf2{w[2].x, w[2].y}, wf2{w[3].x, w[3].y});
+    wf_twiddle16(A1, wf2{w[0].z, w[0].w}, wf2{w[1].z, w[1].w}, wf2{w[2].z, w[2].w}, wf2{w[3].z, w[3].w});
   }
 
   wf2 B0[16], B1[16];
@@ -441,8 +455,16 @@ __device__ __forceinline__ void wf_row(float4 (&px)[16], float4 (&mk)[16],
 // RAW (N2): 1 = u8, 2 = i16 samples conditioned on the fly: `gain` is the (h, row_stride) gain reference
 // (same row pitch as the frames: whole-frame jobs), `job_sub[job]` the per-frame offset, mean_rstd[1]
 // the scale (mc_raw_movie_stats); no statistics are gathered.
+#ifdef MC_K1_STAMP  // in-kernel phase timing of the wave-per-row K1 (s_memtime deltas summed over waves; experiments)
+__device__ unsigned long long g_k1_stamps[16];
+#define KSTAMP(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define KSTAMP_ADD(acc, a, b) (acc) += (b) - (a)
+#else
+#define KSTAMP(v) do { } while (0)
+#define KSTAMP_ADD(acc, a, b) do { } while (0)
+#endif
 template <int KEEP, bool STATS, int N1LO, int N1HI, bool CLAMP_ALL, int WF_PREFETCH, bool HALF = false, int RAW = 0>
-__global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
+__global__ __launch_bounds__(256, WF_MIN_WG) void xc_rows_fwd_wave(
     const void* __restrict__ src, const int64_t* __restrict__ job_off, int64_t row_stride,
     const float* __restrict__ mask, const float* __restrict__ mean_rstd, cfloat* __restrict__ T1,
     const cfloat* __restrict__ tw_row, XcGeom g, XcBox box, double* __restrict__ stats_acc,
@@ -457,6 +479,10 @@ __global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
   const int t = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   wf2* slab = reinterpret_cast<wf2*>(slabs[wv]);
+#ifdef MC_K1_STAMP
+  unsigned long long K0 = 0, K1 = 0, Ka = 0, Kb = 0, Kc = 0, Kd = 0, Ke = 0, Kf = 0, kt_row = 0, kt_park = 0, kt_b1 = 0, kt_st = 0, kt_b2 = 0;
+#endif
+  KSTAMP(K0);
   // Workgroup -> (job, row group): workgroups are dealt round-robin over the 8 XCDs (speed
   // only, MI355X guide), so every job of one row group is sent to the same XCD: its L2 then
   // fetches the group's mask rows once for all jobs instead of once per XCD.
@@ -475,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
       i = i < NTAB ? i : NTAB - 1;
       int src_k;
       if (i < WF_TWA) {
-        src_k = 2 * (i & 127) * ((i >> 7) + 1);
+        src_k = (2 * (i & 127)) << (i >> 7);  // W_2048^{q 2^s} = tw_row[2 q 2^s]
       } else if (i < WF_TWA + WF_TWB) {
         const int e = i - WF_TWA, h = e & 1, k2 = ((e >> 1) % 15) + 1, gq = e / 30;
         src_k = 32 * (2 * gq + h) * k2;
@@ -505,7 +531,8 @@ __global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
   // written once; scattered 16-byte stores cost 2.8x the bytes at the memory side).
   const int r16 = grp * WF_ROWS_PER_WG;
   auto row_of = [&](int i) { return r16 + (i >> 1) * 8 + 2 * wv + (i & 1); };  // i = 0..3
-  const int nrows = g.ny - r16 >= 16 ? 4 : (g.ny - r16 >= 8 ? 2 : 0);  // ny % 8 == 0
+  const int rounds_left = (g.ny - r16) >> 3;  // ny % 8 == 0
+  const int nrows = 2 * (rounds_left < WF_ROWS_PER_WG / 8 ? rounds_left : WF_ROWS_PER_WG / 8);
   float4 px[16], mk[16];
   // clamp bounds of a row's sample loads: the support box, or (CLAMP_ALL with a table) the row's
   // own chord of the mask disk -- the corners of the box, 21 % of it, are then never fetched
@@ -518,6 +545,7 @@ __global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
   if (WF_PREFETCH >= 2 && RAW == 0 && nrows > 0)
     wf_load_mask<N1LO, N1HI>(mask + (int64_t)(g.y0 + row_of(0)) * g.W, t, mk);
   __syncthreads();
+  KSTAMP(K1);
   wf2 Xe[4][KEEP];  // bins of the even row of the current pair
 #pragma unroll 1
   for (int rr = 0; rr < nrows; ++rr) {
@@ -530,10 +558,13 @@ __global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
     const bool in_box_row = STATS && y >= box.hl && y < box.hu;
     wf2 X[4][KEEP];
     const int2 cb = bounds(y), cn = bounds(rr + 1 < nrows ? yn : y);
+    KSTAMP(Ka);
     wf_row<KEEP, STATS, N1LO, N1HI, CLAMP_ALL, WF_PREFETCH, HALF, RAW>(
         px, mk, row, mrow, next_row, next_mrow, t, slab, twA, twB, twK, g, box.wl >> 8,
         in_box_row ? (box.wu >> 8) : 0, mean, rstd, st_s, st_q, X, cb.x, cb.y, cn.x, cn.y,
         RAW ? gain + (int64_t)y * row_stride : nullptr);
+    KSTAMP(Kb);
+    KSTAMP_ADD(kt_row, Ka, Kb);
     if (rr & 1) {
       int ts = t;
       wf_pin(ts, X[0][0].x);  // addresses: computed here, not carried across rows
@@ -550,8 +581,12 @@ __global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
           const int k = L.kbin[s] + 256 * k3;
           if (k < g.nkx) park[k] = make_float4(Xe[s][k3].x, Xe[s][k3].y, X[s][k3].x, X[s][k3].y);
         }
+      KSTAMP(Kc);
+      KSTAMP_ADD(kt_park, Kb, Kc);
       if (!hold) {  // workgroup-uniform
         __syncthreads();
+        KSTAMP(Kd);
+        KSTAMP_ADD(kt_b1, Kc, Kd);
         int tj = threadIdx.x;
         wf_pin(tj, X[0][0].y);
         const float4* parked = reinterpret_cast<const float4*>(&slabs[0][0]);
@@ -577,7 +612,11 @@ __global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
 #endif
           }
         }
+        KSTAMP(Ke);
+        KSTAMP_ADD(kt_st, Kd, Ke);
         __syncthreads();
+        KSTAMP(Kf);
+        KSTAMP_ADD(kt_b2, Ke, Kf);
       }
     } else {
 #pragma unroll
@@ -586,6 +625,14 @@ __global__ __launch_bounds__(256, 2) void xc_rows_fwd_wave(
         for (int k3 = 0; k3 < KEEP; ++k3) Xe[s][k3] = X[s][k3];
     }
   }
+#ifdef MC_K1_STAMP
+  KSTAMP(Kf);
+  if (t == 0) {
+    atomicAdd(&g_k1_stamps[0], K1 - K0); atomicAdd(&g_k1_stamps[1], kt_row); atomicAdd(&g_k1_stamps[2], kt_park);
+    atomicAdd(&g_k1_stamps[3], kt_b1); atomicAdd(&g_k1_stamps[4], kt_st); atomicAdd(&g_k1_stamps[5], kt_b2);
+    atomicAdd(&g_k1_stamps[6], Kf - K0); atomicAdd(&g_k1_stamps[7], 1ull); atomicAdd(&g_k1_stamps[8], (unsigned long long)nrows);
+  }
+#endif
   if constexpr (STATS) {
     double ds = st_s, dq = st_q;
     for (int o = 32; o > 0; o >>= 1) {
@@ -1691,7 +1738,7 @@ static int rows_forward_impl(const float* src, const int64_t* job_off, int64_t r
     // 2.00 -> 1.97 ms per 40 x 4096^2 step) but its 26 KB of extra LDS per workgroup keeps the warp's
     // tiles of the other stream out of the CU: 1.74 -> 1.84 ms per step under the two-stream overlap.
     const size_t park_bytes = (size_t)4 * g.nkx * 16;
-    const int lines16 = (mc_env_on("MC_K1_LINES16") && (g.ny % 16) == 0 && park_bytes <= 27 * 1024 &&
+    const int lines16 = (WF_ROWS_PER_WG == 16 && mc_env_on("MC_K1_LINES16") && (g.ny % 16) == 0 && park_bytes <= 27 * 1024 &&
                          ((reinterpret_cast<uintptr_t>(T1) & 127) == 0)) ? 1 : 0;
     const size_t dyn = lines16 ? park_bytes : 0;
 #define MC_WAVE_LAUNCH(KEEP, ST, LO, HI, CL, PF)                                                  \
@@ -1727,11 +1774,25 @@ static int rows_forward_impl(const float* src, const int64_t* job_off, int64_t r
     else                                                                                    \
       MC_WAVE_LAUNCH(KEEP, ST, 0, 16, true, WF_PREFETCH_DEFAULT);                           \
   } while (0)
+#ifdef MC_K1_STAMP
+    unsigned long long kz[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_k1_stamps), kz, sizeof kz);
+#endif
     if (g.nkx <= 256) {
       if (stats_acc) MC_WAVE_PICK(1, true); else MC_WAVE_PICK(1, false);
     } else {
       if (stats_acc) MC_WAVE_PICK(2, true); else MC_WAVE_PICK(2, false);
     }
+#ifdef MC_K1_STAMP
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    (void)hipMemcpyFromSymbol(kz, HIP_SYMBOL(g_k1_stamps), sizeof kz);
+    if (kz[7] && njobs > 1) {
+      const double wv = (double)kz[7], rows = (double)kz[8];
+      fprintf(stderr, "K1 stamps (memtime ticks): per wave: prologue %.0f total %.0f | per row: transform %.0f | per row pair: "
+              "park %.0f barrier %.0f store %.0f barrier %.0f | waves %.0f rows/wave %.2f\n",
+              kz[0] / wv, kz[6] / wv, kz[1] / rows, 2 * kz[2] / rows, 2 * kz[3] / rows, 2 * kz[4] / rows, 2 * kz[5] / rows, wv, rows / wv);
+    }
+#endif
 #undef MC_WAVE_PICK
 #undef MC_WAVE_LAUNCH
     return mc_check_launch();
