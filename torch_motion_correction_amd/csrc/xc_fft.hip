@@ -598,18 +598,31 @@ __global__ __launch_bounds__(256, WF_MIN_WG) void xc_rows_fwd_wave(
           }
         } else {
           const int r8 = r16 + (rr >> 1) * 8;
-          for (int j = tj; j < 4 * g.nkx; j += 256) {  // 4 lanes = the 64 bytes of one kx
-            const int kx = j >> 2, w = j & 3;
-#ifndef MC_K1_PLAIN_STORES
-            {  // T1 is written once here and read once by K2, 0.4 GB later: non-temporal (K1 0.465 -> 0.455 ms)
-              typedef float f4 __attribute__((ext_vector_type(4)));
-              const float4 pv = parked[w * (WF_SLAB / 2) + kx];
-              const f4 v = {pv.x, pv.y, pv.z, pv.w};
-              __builtin_nontemporal_store(v, reinterpret_cast<f4*>(out + (int64_t)kx * g.ny + r8 + 2 * w));
+          // 4 lanes = the 64 bytes of one kx; nkx <= 256 KEEP, so at most 4 KEEP pieces per thread: all the
+          // LDS reads first, then the stores (one LDS latency per round instead of one per piece)
+          typedef float f4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+          for (int half = 0; half < KEEP; ++half) {  // four pieces (16 registers) at a time
+            float4 pv[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+              const int j = tj + 256 * (4 * half + it);
+              if (j < 4 * g.nkx) pv[it] = parked[(j & 3) * (WF_SLAB / 2) + (j >> 2)];
             }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+              const int j = tj + 256 * (4 * half + it);
+              if (j < 4 * g.nkx) {
+                const int kx = j >> 2, w = j & 3;
+#ifndef MC_K1_PLAIN_STORES
+                // T1 is written once here and read once by K2, 0.4 GB later: non-temporal (K1 0.465 -> 0.455 ms)
+                const f4 v = {pv[it].x, pv[it].y, pv[it].z, pv[it].w};
+                __builtin_nontemporal_store(v, reinterpret_cast<f4*>(out + (int64_t)kx * g.ny + r8 + 2 * w));
 #else
-            *reinterpret_cast<float4*>(out + (int64_t)kx * g.ny + r8 + 2 * w) = parked[w * (WF_SLAB / 2) + kx];
+                *reinterpret_cast<float4*>(out + (int64_t)kx * g.ny + r8 + 2 * w) = pv[it];
 #endif
+              }
+            }
           }
         }
         KSTAMP(Ke);
