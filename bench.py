@@ -287,8 +287,10 @@ def main():
             shr = (lastr.field[:, :, 0, 0].transpose(0, 1) / 1.0).cpu()
             del rr, lastr
 
+            ncond = min(nraw, 10)  # (more steps only measure the caching allocator: every step takes a fresh 2.7 GB movie)
+
             def conditioned():
-                for i in range(nraw):
+                for i in range(ncond):
                     yield mc.condition_movie([ra, rb][i % 2], gain)
 
             for _ in pipe.iterate(mc.condition_movie(x, gain) for x in (ra, rb, ra)):
@@ -307,7 +309,7 @@ def main():
                 "frames_per_s": t * nraw / el_raw, "ms_per_step": 1e3 * el_raw / nraw, "steps": nraw,
                 "peak_extra_hbm_GB": peak_raw / 1e9,
                 "shifts_match_ground_truth": bool(torch.equal(shr, expect)),
-                "via_fp32_movie_ms_per_step": 1e3 * el_cond / nraw, "via_fp32_movie_peak_extra_hbm_GB": peak_cond / 1e9,
+                "via_fp32_movie_ms_per_step": 1e3 * el_cond / ncond, "via_fp32_movie_peak_extra_hbm_GB": peak_cond / 1e9,
                 # compulsory bytes of the raw flow: the u8 frame read by the statistics, the estimator and the
                 # corrector, the corrected fp32 frame written once
                 "whole_step_frac_of_7_bytes_per_px": 7.0 * h * w * t / (el_raw / nraw) / 1e9 / HBM_PEAK_GBS,
