@@ -999,9 +999,22 @@ __global__ __launch_bounds__(MC_WG) void xc_cols_fwd(const cfloat* __restrict__ 
 // K3: only the kept input rows are fetched (n1 in {0, 1, 14, 15} of the first radix-16 pass);
 //     the inverse runs the forward kernel on conjugated data.
 #define XC_FWDW_COLS 1  // columns per wavefront in xc_cols_fwd_wave1024 (4 measured slower: the kernel streams T1 at 3.2 TB/s)
-__device__ __forceinline__ void wf10_passes_ab(wf2 (&a)[16], int t, wf2* slab, const cfloat* __restrict__ tw,
+// The six table entries a lane needs (they depend on the lane only): loaded once, up front -- behind the
+// acquire fence of wf_sync the compiler cannot start them early, and a wave waited for the L2 in the middle of
+// every column.
+struct Wf10Tw {
+  wf2 w1, w2, w4, w8, b[2];
+};
+__device__ __forceinline__ Wf10Tw wf10_twiddles(int t, const cfloat* __restrict__ tw) {
+  Wf10Tw T;
+  T.w1 = wf_from(tw[t]); T.w2 = wf_from(tw[2 * t]); T.w4 = wf_from(tw[4 * t]); T.w8 = wf_from(tw[8 * t]);
+  T.b[0] = wf_from(tw[16 * (t >> 4)]);
+  T.b[1] = wf_from(tw[16 * ((t >> 4) + 4)]);
+  return T;
+}
+__device__ __forceinline__ void wf10_passes_ab(wf2 (&a)[16], int t, wf2* slab, const Wf10Tw& T,
                                                wf2 (&B)[2][8]) {
-  wf_twiddle16(a, wf_from(tw[t]), wf_from(tw[2 * t]), wf_from(tw[4 * t]), wf_from(tw[8 * t]));
+  wf_twiddle16(a, T.w1, T.w2, T.w4, T.w8);
 #pragma unroll
   for (int k1 = 0; k1 < 16; ++k1) slab[wf10_x1(k1, t)] = a[k1];
   wf_sync();
@@ -1016,7 +1029,7 @@ __device__ __forceinline__ void wf10_passes_ab(wf2 (&a)[16], int t, wf2* slab, c
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     wf_dft8(B[b]);
-    wf_twiddle8(B[b], wf_from(tw[16 * ((t >> 4) + 4 * b)]));  // W_64^{n3 k2}
+    wf_twiddle8(B[b], T.b[b]);  // W_64^{n3 k2}
 #pragma unroll
     for (int k2 = 0; k2 < 8; ++k2) slab[wf10_x2(k1, k2, (t >> 4) + 4 * b)] = B[b][k2];
   }
@@ -1037,6 +1050,7 @@ __global__ __launch_bounds__(256) void xc_cols_fwd_wave1024(const cfloat* __rest
   wf2* slab = slabs[wv];
   const int nky = g.kyp + g.kyn;
   const float dmean = fix ? fix[0] : 0.f, rstd = fix ? fix[1] : 1.f;
+  const Wf10Tw TW = wf10_twiddles(threadIdx.x & 63, tw_col);
 #pragma unroll 1
   for (int cc = 0; cc < XC_FWDW_COLS; ++cc) {
   const int kx = kx0 + cc;
@@ -1054,8 +1068,24 @@ __global__ __launch_bounds__(256) void xc_cols_fwd_wave1024(const cfloat* __rest
     const int yy = 64 * n1 + t - g.y0;
     a[n1] = (yy >= 0 && yy < g.ny) ? wf_from(col[yy]) : wf2{0.f, 0.f};
   }
+  // filter and mask-spectrum values of the (at most four) rows this lane stores: fetched with the samples
+  int kyo[2][2];
+  float fpre[2][2];
+  cfloat mpre[2][2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int sel = 0; sel < 2; ++sel) {
+      const int ky = (t & 15) + 16 * ((t >> 4) + 4 * b) + (sel ? 896 : 0);
+      int kyi = -1;
+      if (ky < g.kyp) kyi = ky;
+      else if (ky >= H - g.kyn) kyi = ky - (H - g.kyn) + g.kyp;
+      kyo[b][sel] = kyi;
+      fpre[b][sel] = (f && kyi >= 0) ? f[kyi] : 1.f;
+      mpre[b][sel] = (fix && kyi >= 0) ? mh[kyi] : cmake(0.f, 0.f);
+    }
   wf_dft16(a);
-  wf10_passes_ab(a, t, slab, tw_col, B);
+  wf10_passes_ab(a, t, slab, TW, B);
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const int k1 = t & 15, k2 = (t >> 4) + 4 * b;
@@ -1067,20 +1097,13 @@ __global__ __launch_bounds__(256) void xc_cols_fwd_wave1024(const cfloat* __rest
     }
     wf_sync();
     wf_dft8_pruned<1>(e, o, z);  // k3 = 0 and 7
-    const int c = k1 + 16 * k2;  // ky = c (k3 = 0) and c + 896 (k3 = 7)
 #pragma unroll
     for (int sel = 0; sel < 2; ++sel) {
-      const int ky = sel ? c + 896 : c;
-      int kyi = -1;
-      if (ky < g.kyp) kyi = ky;
-      else if (ky >= H - g.kyn) kyi = ky - (H - g.kyn) + g.kyp;
+      const int kyi = kyo[b][sel];
       if (kyi >= 0) {
         cfloat v = wf_to(z[sel ? 7 : 0]);
-        if (fix) {
-          const cfloat m = mh[kyi];
-          v = cmake((v.x - dmean * m.x) * rstd, (v.y - dmean * m.y) * rstd);
-        }
-        out[kyi] = f ? cscale(v, f[kyi]) : v;
+        if (fix) v = cmake((v.x - dmean * mpre[b][sel].x) * rstd, (v.y - dmean * mpre[b][sel].y) * rstd);
+        out[kyi] = f ? cscale(v, fpre[b][sel]) : v;
       }
     }
   }
@@ -1114,8 +1137,9 @@ __global__ __launch_bounds__(256) void xc_cols_inv_wave1024(
       }
     }
   }
+  const Wf10Tw TW = wf10_twiddles(t, tw_col);
   wf_dft16(a);
-  wf10_passes_ab(a, t, slab, tw_col, B);
+  wf10_passes_ab(a, t, slab, TW, B);
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const int k1 = t & 15, k2 = (t >> 4) + 4 * b;
@@ -1148,14 +1172,30 @@ __global__ __launch_bounds__(256) void xc_cols_inv_near_wave1024(
   float acc[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  // twiddles once per wave; a column's eight input values are fetched while the previous column is
+  // transformed (as xc_cols_inv_near does: the kernel waited, exposed, at the head of every column)
+  const Wf10Tw TW = wf10_twiddles(t, tw_col);
+  const int64_t cur_base = (int64_t)cur_idx[p] * g.nkx, ref_base = (int64_t)ref_idx[p] * g.nkx;
+  int kyi4[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) kyi4[s4] = kept_index(64 * (s4 < 2 ? s4 : s4 + 12) + t, H, g.kyp, g.kyn);
+  cfloat pc[4], pr[4];
+  auto fetch4 = [&](int kx, cfloat (&c4)[4], cfloat (&r4)[4]) {
+    const cfloat* cur = S_cur + (cur_base + kx) * nky;
+    const cfloat* ref = S_ref + (ref_base + kx) * nky;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      c4[s4] = kyi4[s4] >= 0 ? cur[kyi4[s4]] : cmake(0.f, 0.f);
+      r4[s4] = kyi4[s4] >= 0 ? ref[kyi4[s4]] : cmake(0.f, 0.f);
+    }
+  };
+  fetch4(kx0, pc, pr);
 #pragma unroll 1
   for (int cc = 0; cc < XC_NEAR_COLS_W; ++cc) {
     const int kx = kx0 + cc;
     if (kx >= g.nkx) break;  // wave-uniform
     int tl = t;  // opaque per column: nothing derived from it is hoisted (registers)
     asm volatile("" : "+v"(tl));
-    const cfloat* cur = S_cur + ((int64_t)cur_idx[p] * g.nkx + kx) * nky;
-    const cfloat* ref = S_ref + ((int64_t)ref_idx[p] * g.nkx + kx) * nky;
     cfloat* outn = T2n + ((int64_t)p * g.nkx + kx) * (2 * nstore);
     const float wgt = kx == 0 ? 1.f : 2.f;
     wf2 a[16], B[2][8];
@@ -1163,15 +1203,14 @@ __global__ __launch_bounds__(256) void xc_cols_inv_near_wave1024(
     for (int n1 = 0; n1 < 16; ++n1) {
       a[n1] = wf2{0.f, 0.f};
       if (n1 < 2 || n1 >= 14) {
-        const int kyi = kept_index(64 * n1 + tl, H, g.kyp, g.kyn);
-        if (kyi >= 0) {
-          const cfloat v = cscale(cmulc(ref[kyi], cur[kyi]), scale);
-          a[n1] = wf2{v.x, -v.y};
-        }
+        const int s4 = n1 < 2 ? n1 : n1 - 12;
+        const cfloat v = cscale(cmulc(pr[s4], pc[s4]), scale);  // zero where the row is not kept
+        a[n1] = wf2{v.x, -v.y};
       }
     }
-    wf_dft16(a);
-    wf10_passes_ab(a, tl, slab, tw_col, B);
+    if (cc + 1 < XC_NEAR_COLS_W && kx + 1 < g.nkx) fetch4(kx + 1, pc, pr);
+    wf_dft16_lo2(a);  // entries 2..13 are zero
+    wf10_passes_ab(a, tl, slab, TW, B);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const int k1 = tl & 15, k2 = (tl >> 4) + 4 * b;
