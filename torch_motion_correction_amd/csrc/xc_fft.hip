@@ -680,6 +680,9 @@ __global__ __launch_bounds__(256, WF_MIN_WG) void xc_rows_fwd_wave(
 #define WF5_TWA (7 * 64)
 #define WF5_TWB (8 * 7)
 #define WF5_TWK 128
+#ifndef WF5_MIN_WAVES
+#define WF5_MIN_WAVES 5  // waves per SIMD the register allocation aims at (DUAL fp32 sits at 97 VGPRs without it: 4)
+#endif
 #define WF5_ROWS_PER_WG 32  // rounds of 8 rows: wave wv takes rows 2 wv and 2 wv + 1 of a round
 
 __device__ __forceinline__ wf2 wf5_ld2(const float* p) {  // 4-byte aligned 8-byte load
@@ -734,7 +737,7 @@ __device__ __forceinline__ void wf5_fft(wf2 (&A)[8], int t, wf2* slab, const wf2
 }
 
 template <bool DUAL, bool HALF>
-__global__ __launch_bounds__(256) void xc_rows_fwd_wave512(
+__global__ __launch_bounds__(256, WF5_MIN_WAVES) void xc_rows_fwd_wave512(
     const void* __restrict__ src_any, const int64_t* __restrict__ job_off, int64_t row_stride,
     const int* __restrict__ expo_a, const int* __restrict__ expo_b, const float* __restrict__ mask,
     const float* __restrict__ mean_rstd, cfloat* __restrict__ T1a, cfloat* __restrict__ T1b,
@@ -801,7 +804,13 @@ __global__ __launch_bounds__(256) void xc_rows_fwd_wave512(
     }
 #pragma unroll
     for (int n1 = 0; n1 < 8; ++n1) A[n1] = (A[n1] - mean) * rstd;
-    {  // mask^ea and mask^eb: wave-uniform trip counts, kept out of the load loop
+    if (DUAL && ea == 1 && eb == 2) {  // the leave-one-out schedule's only pair: mask and mask^2, no power loop
+#pragma unroll
+      for (int n1 = 0; n1 < 8; ++n1) {
+        A[n1] = A[n1] * mk[n1];
+        Bv[n1] = A[n1] * mk[n1];
+      }
+    } else {  // mask^ea and mask^eb: wave-uniform trip counts, kept out of the load loop
       wf2 pw[8];
 #pragma unroll
       for (int n1 = 0; n1 < 8; ++n1) pw[n1] = mk[n1];
