@@ -1007,6 +1007,9 @@ __global__ __launch_bounds__(MC_WG) void xc_cols_fwd(const cfloat* __restrict__ 
 // K2: only the kept output rows are produced (k3 in {0, 7} of the last radix-8 pass).
 // K3: only the kept input rows are fetched (n1 in {0, 1, 14, 15} of the first radix-16 pass);
 //     the inverse runs the forward kernel on conjugated data.
+#ifndef XC_NEAR_MIN_WAVES
+#define XC_NEAR_MIN_WAVES 4  // register target of the near-window column passes (5: 96 VGPRs, spills)
+#endif
 #define XC_FWDW_COLS 1  // columns per wavefront in xc_cols_fwd_wave1024 (4 measured slower: the kernel streams T1 at 3.2 TB/s)
 // The six table entries a lane needs (they depend on the lane only): loaded once, up front -- behind the
 // acquire fence of wf_sync the compiler cannot start them early, and a wave waited for the L2 in the middle of
@@ -1165,7 +1168,7 @@ __global__ __launch_bounds__(256) void xc_cols_inv_wave1024(
 // columns of one pair, keeps the stored window's rows and its share of the row bounds (16 rows
 // per lane, in registers over the column loop).
 #define XC_NEAR_COLS_W 8
-__global__ __launch_bounds__(256) void xc_cols_inv_near_wave1024(
+__global__ __launch_bounds__(256, XC_NEAR_MIN_WAVES) void xc_cols_inv_near_wave1024(
     const cfloat* __restrict__ S_cur, const int* __restrict__ cur_idx,
     const cfloat* __restrict__ S_ref, const int* __restrict__ ref_idx, cfloat* __restrict__ T2n,
     float* __restrict__ bounds, const cfloat* __restrict__ tw_col, float scale, XcGeom g, int nstore) {
@@ -1306,7 +1309,7 @@ __global__ __launch_bounds__(MC_WG) void xc_cols_inv(
 #endif
 #define XC_NEAR_GUARD 8  // extra stored rows per end: neighbourhood of a peak on the window's edge
 template <int LOGH, bool R16 = false>
-__global__ __launch_bounds__(MC_WG) void xc_cols_inv_near(
+__global__ __launch_bounds__(MC_WG, XC_NEAR_MIN_WAVES) void xc_cols_inv_near(
     const cfloat* __restrict__ S_cur, const int* __restrict__ cur_idx,
     const cfloat* __restrict__ S_ref, const int* __restrict__ ref_idx, cfloat* __restrict__ T2n,
     float* __restrict__ bounds, const cfloat* __restrict__ tw_col, float scale, XcGeom g, int nstore) {
