@@ -1529,9 +1529,21 @@ __global__ __launch_bounds__(MC_WG) void xc_rows_inv(const cfloat* __restrict__ 
   const int coff = (int)blockIdx.x < near ? (int)blockIdx.x * RG
                                           : nstore + (compact - 1) + ((int)blockIdx.x - near) * RG;
   const cfloat* in = T2 + (int64_t)p * g.nkx * cstride + (int64_t)(compact ? coff : grp * RG);
-  for (int i = tid; i < g.nkx * RG; i += MC_WG) {
-    const int kx = i / RG, r = i - kx * RG;
-    stg[kx * (RG + 1) + r] = in[(int64_t)kx * cstride + r];
+  // eight loads in flight per thread (the one-at-a-time loop waited for the L2 up to 13 times in a row)
+  for (int i0 = tid; i0 < g.nkx * RG; i0 += 8 * MC_WG) {
+    cfloat v8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * MC_WG;
+      const int kx = i / RG, r = i - kx * RG;
+      if (i < g.nkx * RG) v8[u] = in[(int64_t)kx * cstride + r];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * MC_WG;
+      const int kx = i / RG, r = i - kx * RG;
+      if (i < g.nkx * RG) stg[kx * (RG + 1) + r] = v8[u];
+    }
   }
   FftTwiddles<N> T;
   T.template init<+1>(lt, tw_row, 2);
