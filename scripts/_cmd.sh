@@ -1,10 +1,7 @@
 cd $GRAFT_REPO_ROOT
-for tag in base r16 base r16; do
-  if [ $tag = base ]; then export MCORR_LIB=$PWD/torch_motion_correction_amd/libmcorr.so; else export MCORR_LIB=$PWD/variants/$tag/libmcorr.so; fi
-  for st in 20 60; do
-  python bench.py --steps $st --warmup 5 --no-secondary --no-cpu-baseline 2>&1 | python -c "
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "
 import sys, json
-for l in sys.stdin:
-    if l.startswith('{'):
-        d = json.loads(l); print('$tag', $st, d['ms_per_step'], d['value'], d['roofline']['frac'], d['roofline'].get('whole_step_frac'))
-"; done; done
+d=json.loads(sys.stdin.read())
+print(d['value'], d['ms_per_step'], d['roofline']['whole_step_frac'])
+print(d['raw_u8'])
+"
