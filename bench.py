@@ -134,7 +134,8 @@ def main():
 
     def run_steps(n, record):
         last = None
-        engine.RIGID_KERNEL_HOOK = timed_warp if record else None  # events around warp_rigid_dma alone
+        # events around warp_rigid_dma alone (MC_BENCH_NO_EVENTS=1, an A/B knob, times the region without them)
+        engine.RIGID_KERNEL_HOOK = timed_warp if record and os.environ.get("MC_BENCH_NO_EVENTS") != "1" else None
         try:
             for res in pipe.iterate([stack, stack_b][i % 2] for i in range(n)):
                 last = res  # earlier results are dropped: their memory is reused by the next step
@@ -201,9 +202,9 @@ def main():
             copy_rate = None
     shifts = (out.field[:, :, 0, 0].transpose(0, 1) / 1.0).cpu()
     shifts_ok = bool(torch.equal(shifts, expect))
-    warp_ms = sum(a.elapsed_time(b) for a, b in warp_events) / max(len(warp_events), 1)
+    warp_ms = sum(a.elapsed_time(b) for a, b in warp_events) / max(len(warp_events), 1) if warp_events else float("nan")
     alg_bytes = 8.0 * h * w * t  # read + write of every frame, once
-    achieved = alg_bytes / (warp_ms * 1e-3) / 1e9
+    achieved = alg_bytes / (warp_ms * 1e-3) / 1e9 if warp_events else float("nan")
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # N = 1 only (contract)

@@ -1,7 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "
-import sys, json
-d=json.loads(sys.stdin.read())
-print(d['value'], d['ms_per_step'], d['roofline']['whole_step_frac'])
-print(d['raw_u8'])
-"
+for s in k1first all; do echo "== schedule $s"; MC_PIPE_SCHEDULE=$s timeout -k 10 300 python scripts/cumask_probe.py 2>&1 | grep -v amdgpu.ids; done
